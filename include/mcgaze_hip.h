@@ -1,0 +1,183 @@
+/*
+ * mcgaze_hip.h -- C-ABI of libmcgaze_hip.so, the MI355X (gfx950) implementation of the
+ * MCGaze per-clip forward path.
+ *
+ * The reference has NO in-tree native code and no FFI for this path:
+ * the arithmetic is reached through torch / mmcv Python calls.  Each entry point below
+ * therefore cites the reference *Python* interface (file:line, relative to the upstream
+ * repo root) whose work it replaces; INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add at that call site.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*
+ *   - every call enqueues work on the caller's HIP stream and returns without host sync
+ *   - no allocation on the hot path: scratch comes from a caller-provided workspace
+ *   - return value: MCG_OK or an MCG_ERR_* code; mcg_last_error() gives the message
+ *   - activations are NHWC ("channels last"): [frame][y][x][channel]; dtype is MCG_F32
+ *     (parity mode, f32 MFMA, exact f32 accumulate chains) or MCG_BF16 (throughput mode,
+ *     bf16 MFMA, f32 accumulate).  Bias / LayerNorm parameters / boxes are always f32.
+ *   - conv / linear weights are "OHWI": [Cout][KH][KW][Cin] (K contiguous), BN folded in.
+ */
+#ifndef MCGAZE_HIP_H
+#define MCGAZE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCG_ABI_VERSION 1
+
+enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
+typedef enum { MCG_F32 = 0, MCG_BF16 = 1 } mcg_dtype;
+typedef void* mcg_stream; /* hipStream_t */
+
+int mcg_abi_version(void);
+const char* mcg_last_error(void);
+/* Fills CU count, HBM bytes and the gcnArchName of the current HIP device. */
+int mcg_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len);
+
+/* ---------------------------------------------------------------- layout helpers */
+/* [N,C,H,W] f32 (the tensor the reference hands to backbone(img), multiclue_gaze.py:35)
+ * -> NHWC dtype. */
+int mcg_nchw_to_nhwc(mcg_stream s, mcg_dtype dt, const float* src, void* dst, int N, int C, int H, int W);
+/* NHWC dtype -> [N,C,H,W] f32 (for handing a pyramid level back to NCHW consumers). */
+int mcg_nhwc_to_nchw(mcg_stream s, mcg_dtype dt, const void* src, float* dst, int N, int C, int H, int W);
+
+/* ---------------------------------------------------------------- conv / linear (implicit GEMM on MFMA)
+ * Replaces, with BN folded and the activation fused:
+ *   conv+BN+ReLU of Bottleneck.forward            mmdet/models/backbones/resnet.py:263-302
+ *   downsample conv+BN                             mmdet/models/utils/res_layer.py:51-61
+ *   FPN lateral / output convs + top-down add      mmdet/models/necks/fpn.py:157-180
+ *   every nn.Linear of the decoder (H=W=1)         gaze_stqi_head.py:151-201, transformer.py:1131-1162
+ */
+enum { MCG_RES_NONE = 0, MCG_RES_ADD = 1, MCG_RES_UPSAMPLE_ADD = 2 };
+typedef struct {
+  const void* x;        /* NHWC [N,H,W,Cin]                                         */
+  const void* w;        /* OHWI [Cout,KH,KW,Cin]                                    */
+  const float* bias;    /* [Cout] or NULL                                           */
+  const void* residual; /* MCG_RES_ADD: [N,Ho,Wo,Cout]; UPSAMPLE_ADD: [N,Hr,Wr,Cout] */
+  void* y;              /* NHWC [N,Ho,Wo,Cout]                                      */
+  int N, H, W, Cin, Cout, KH, KW, stride, pad;
+  int relu;             /* 1: y = max(y, 0) after bias and residual                 */
+  int residual_mode;    /* MCG_RES_*                                                */
+  int Hr, Wr;           /* residual spatial size for UPSAMPLE_ADD (nearest, F.interpolate size=) */
+} mcg_conv_desc;
+int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);
+
+/* Stem: conv 7x7 s2 p3 (3->64) + BN + ReLU then max-pool 3x3 s2 p1 (resnet.py:636-639).
+ * img is the reference's NCHW f32 frame tensor.  w_stem is the packed stem weight
+ * [64][7][8][4] (kw and channel zero-padded, BN folded).  ws >= mcg_stem_workspace_bytes. */
+size_t mcg_stem_workspace_bytes(mcg_dtype dt, int N, int H, int W);
+int mcg_stem_forward(mcg_stream s, mcg_dtype dt, const float* img, const void* w_stem, const float* bias,
+                     void* y, int N, int H, int W, void* ws, size_t ws_bytes);
+
+/* ---------------------------------------------------------------- RoIAlign, all levels, one launch
+ * Replaces SingleRoIExtractor.forward (roi_extractors/single_level_roi_extractor.py:57-115:
+ * map_roi_levels + per-level mmcv.ops.RoIAlign(7, 1/stride, sampling_ratio=2, 'avg', aligned=True))
+ * and bbox2roi (mmdet/core/bbox/transforms.py:75-94).
+ * boxes [N*P,4] f32 xyxy in image pixels, P boxes per frame, frame index = row / P.
+ * out is [N*P][49][C] dtype (position-major, channel-minor: the layout DynamicConv consumes,
+ * transformer.py:1131-1133).  levels_out (optional) receives the chosen pyramid level per box. */
+int mcg_roi_align(mcg_stream s, mcg_dtype dt, const void* const feats[4], const int feat_h[4], const int feat_w[4],
+                  const int strides[4], int C, const float* boxes, int num_boxes, int boxes_per_frame,
+                  void* out, int32_t* levels_out);
+
+/* ---------------------------------------------------------------- decoder stage / gaze head / whole path
+ * Weight tables are arrays of device pointers indexed by the enums below.  Matrices are
+ * dtype, [out][in] row-major exactly as in the checkpoint unless noted; vectors are f32.
+ */
+enum {
+  MCG_SW_IN_PROJ_W = 0, MCG_SW_IN_PROJ_B, MCG_SW_OUT_PROJ_W, MCG_SW_OUT_PROJ_B, MCG_SW_ATTN_LN_G, MCG_SW_ATTN_LN_B,
+  MCG_SW_DYN_W,      /* dynamic_layer.weight rows permuted so param_in comes out [64][256] and param_out [256][64] (K contiguous) */
+  MCG_SW_DYN_B,      /* permuted the same way, f32 */
+  MCG_SW_NORM_IN_G, MCG_SW_NORM_IN_B, MCG_SW_NORM_OUT_G, MCG_SW_NORM_OUT_B,
+  MCG_SW_FC_W, MCG_SW_FC_B, MCG_SW_FC_LN_G, MCG_SW_FC_LN_B, MCG_SW_IIC_LN_G, MCG_SW_IIC_LN_B,
+  MCG_SW_FFN1_W, MCG_SW_FFN1_B, MCG_SW_FFN2_W, MCG_SW_FFN2_B, MCG_SW_FFN_LN_G, MCG_SW_FFN_LN_B,
+  MCG_SW_CLS_FC_W, MCG_SW_CLS_LN_G, MCG_SW_CLS_LN_B,
+  MCG_SW_REG_FC_W,   /* [3][256][256] */
+  MCG_SW_REG_LN_G,   /* [3][256] */
+  MCG_SW_REG_LN_B,
+  MCG_SW_HEAD_CLS_W, /* f32 [3 clues][256]      (face, eyes, head)_fc_cls.weight */
+  MCG_SW_HEAD_CLS_B, /* f32 [3]                                                  */
+  MCG_SW_HEAD_REG_W, /* f32 [3 clues][4][256]   (face, eyes, head)_fc_reg.weight */
+  MCG_SW_HEAD_REG_B, /* f32 [3][4]                                               */
+  MCG_SW_COUNT
+};
+enum {
+  MCG_GW_FC_W = 0,   /* [6 branches][2 layers][256][256]; branch = 3*k + clue, k = 0 gaze MLP, 1 confidence MLP */
+  MCG_GW_LN_G,       /* f32 [6][2][256] */
+  MCG_GW_LN_B,
+  MCG_GW_OUT_W,      /* f32 [6][3][256]: fc_{clue} (gaze) / fc_{clue}_confidence */
+  MCG_GW_OUT_B,      /* f32 [6][3] */
+  MCG_GW_FUSE_W,     /* f32 [3][9]  fc_gaze */
+  MCG_GW_FUSE_B,     /* f32 [3] */
+  MCG_GW_COUNT
+};
+
+/* One GazeSTQIHead.forward + refine_bboxes (gaze_stqi_head.py:119-202, bbox_head.py:380-457,
+ * delta_xywh_bbox_coder.py:224-260 with stds (.5,.5,1,1), clip_border=False).
+ *   roi_feat [R][49][256] dtype (from mcg_roi_align), obj_in/obj_out [N][3][256] dtype,
+ *   boxes_in/boxes_out [N][3][4] f32, cls_out [N][3] f32 (logits, pre-sigmoid).
+ *   N = num_clips * clip_length frames; temporal attention spans clip_length frames. */
+size_t mcg_stage_workspace_bytes(mcg_dtype dt, int num_frames);
+int mcg_stage_forward(mcg_stream s, mcg_dtype dt, const void* const weights[MCG_SW_COUNT], const void* roi_feat,
+                      const void* obj_in, const float* boxes_in, int num_frames, int clip_length,
+                      void* obj_out, float* boxes_out, float* cls_out, const float bbox_stds[4],
+                      void* ws, size_t ws_bytes);
+
+/* GazeHead.forward (mask_heads/gaze_head.py:138-202): obj [N][3][256] dtype -> gaze [4][N][3] f32
+ * unit vectors in the order fused, face, eyes, head. */
+size_t mcg_gaze_head_workspace_bytes(mcg_dtype dt, int num_frames);
+int mcg_gaze_head(mcg_stream s, mcg_dtype dt, const void* const weights[MCG_GW_COUNT], const void* obj,
+                  int num_frames, float* gaze_out, void* ws, size_t ws_bytes);
+
+/* ---------------------------------------------------------------- engine: the whole path in one call
+ * Replaces MultiClueGaze.simple_test (mmdet/models/detectors/multiclue_gaze.py:105-131) with
+ * the batched semantics of forward_train (:77-78): N = num_clips*clip_length frames.
+ */
+typedef struct {
+  const void* w;      /* OHWI dtype, BN folded */
+  const float* bias;  /* f32 [Cout] */
+  int cin, cout, k, stride, pad;
+} mcg_conv_weights;
+
+typedef struct {
+  int blocks[4];                    /* bottlenecks per layer, (3,4,6,3) for R-50 */
+  mcg_conv_weights stem;            /* packed stem, see mcg_stem_forward */
+  const mcg_conv_weights* convs;    /* host array, execution order: per block conv1, conv2, conv3[, downsample] */
+  int num_convs;
+  mcg_conv_weights lateral[4];
+  mcg_conv_weights fpn_out[4];
+  const float* init_boxes;          /* f32 [3][4] normalised cxcywh (rpn_head.init_proposal_bboxes.weight) */
+  const void* init_feats;           /* dtype [3][256] */
+  int num_stages;
+  const void* const* stage_weights; /* host array [num_stages][MCG_SW_COUNT] of device pointers */
+  const void* const* gaze_weights;  /* host array [MCG_GW_COUNT]: the LAST stage's gaze head */
+  float bbox_stds[4];
+} mcg_model_weights;
+
+typedef struct mcg_engine mcg_engine;
+/* The engine copies the weight TABLES (not the weights); device buffers stay caller-owned. */
+int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, mcg_dtype dt);
+void mcg_engine_destroy(mcg_engine* e);
+/* chunk_frames: the trunk runs in chunks of this many frames so that layer outputs stay
+ * resident in the 256 MiB Infinity Cache (0 = all frames in one pass). */
+size_t mcg_engine_workspace_bytes(const mcg_engine* e, int num_frames, int H, int W, int chunk_frames);
+/* Backbone + FPN only: img NCHW f32 [N,3,H,W] -> P2..P5 NHWC dtype. */
+int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s, const float* img, int num_frames, int H, int W,
+                             int chunk_frames, void* const pyramid[4], void* ws, size_t ws_bytes);
+/* Whole path.  img_hw: DEVICE int [num_frames][2] = img_shape (h, w) per frame, or NULL when every
+ * frame fills the padded H x W (query boxes scale with img_shape, fixed_embedding_rpn_head.py:80-89).
+ * Outputs (device, f32):
+ *   gaze_out [4][N][3] (fused, face, eyes, head), boxes_out [N][3][4], scores_out [N][3] (sigmoid). */
+int mcg_clip_forward(mcg_engine* e, mcg_stream s, const float* img, int num_frames, int clip_length, int H, int W,
+                     const int* img_hw, int chunk_frames, float* gaze_out, float* boxes_out, float* scores_out,
+                     void* ws, size_t ws_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCGAZE_HIP_H */

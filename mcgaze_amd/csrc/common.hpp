@@ -1,0 +1,117 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mcgaze_hip.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef uint16_t bf16_t;  // storage type of a bf16 element
+
+#define MCG_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kPerChunk = 4;  // elements in a 16-byte chunk
+  static constexpr mcg_dtype kDtype = MCG_F32;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kPerChunk = 8;
+  static constexpr mcg_dtype kDtype = MCG_BF16;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte chunk <-> floats
+__device__ __forceinline__ void chunk_to_f32(const uint4& c, float (&v)[4], float*) {
+  v[0] = __uint_as_float(c.x); v[1] = __uint_as_float(c.y); v[2] = __uint_as_float(c.z); v[3] = __uint_as_float(c.w);
+}
+__device__ __forceinline__ void chunk_to_f32(const uint4& c, float (&v)[8], bf16_t*) {
+  v[0] = __uint_as_float(c.x << 16); v[1] = __uint_as_float(c.x & 0xffff0000u);
+  v[2] = __uint_as_float(c.y << 16); v[3] = __uint_as_float(c.y & 0xffff0000u);
+  v[4] = __uint_as_float(c.z << 16); v[5] = __uint_as_float(c.z & 0xffff0000u);
+  v[6] = __uint_as_float(c.w << 16); v[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 f32_to_chunk(const float (&v)[4], float*) {
+  return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+__device__ __forceinline__ uint4 f32_to_chunk(const float (&v)[8], bf16_t*) {
+  return make_uint4((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16),
+                    (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16), (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16));
+}
+
+// One 32x32 MFMA "chunk pair" step: each lane holds 16 bytes of A (row lane&31) and 16 bytes of B
+// (column lane&31) taken from K-chunk 2j + (lane>>5).  bf16: one v_mfma_f32_32x32x16_bf16.
+// f32: four v_mfma_f32_32x32x2_f32 (exact f32 fma chain); the K order inside the pair is
+// permuted identically for A and B, which leaves the dot product's term set unchanged.
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  __device__ static __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  __device__ static __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+
+// C/D element (reg r of lane l) of a 32x32 MFMA tile: col = l & 31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+__device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): give each XCD a contiguous run of
+// logical tile ids so that tiles sharing an operand panel meet in one L2.  Bijective for any grid.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------- host side error plumbing
+void mcg_set_error(const char* fmt, ...);
+#define MCG_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      mcg_set_error(__VA_ARGS__);       \
+      return MCG_ERR_ARG;               \
+    }                                   \
+  } while (0)
+#define MCG_CHECK_LAUNCH(what)                                                       \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      mcg_set_error("%s: %s", what, hipGetErrorString(e__));                         \
+      return MCG_ERR_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+#define MCG_TRY(expr)                 \
+  do {                                \
+    int rc__ = (expr);                \
+    if (rc__ != MCG_OK) return rc__;  \
+  } while (0)

@@ -1,0 +1,225 @@
+// Engine: enqueues the whole per-clip forward path (trunk -> query init -> 4 x [RoIAlign + decoder
+// stage] -> gaze head) on one HIP stream from a single C-ABI call.  No allocation, no host sync:
+// every intermediate lives in the caller-provided workspace.
+#include "igemm.hpp"
+
+#include <string.h>
+
+#include <vector>
+
+int launch_roi_align(hipStream_t s, mcg_dtype dt, const void* const feats[4], const int feat_h[4], const int feat_w[4],
+                     const int strides[4], int C, const float* boxes, int num_boxes, int boxes_per_frame, void* out,
+                     int32_t* levels_out);
+int launch_init_queries(hipStream_t s, mcg_dtype dt, const float* init_boxes, const void* init_feats, const int* img_hw, int H, int W,
+                        float* boxes, void* obj, int N);
+int launch_sigmoid(hipStream_t s, const float* x, float* y, int n);
+
+struct mcg_engine {
+  mcg_dtype dt;
+  int blocks[4];
+  mcg_conv_weights stem;
+  std::vector<mcg_conv_weights> convs;
+  mcg_conv_weights lateral[4], fpn_out[4];
+  const float* init_boxes;
+  const void* init_feats;
+  int num_stages;
+  std::vector<const void*> stage_w;  // [num_stages][MCG_SW_COUNT]
+  const void* gaze_w[MCG_GW_COUNT];
+  float stds[4];
+};
+
+static inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
+static inline size_t esize(mcg_dtype dt) { return dt == MCG_BF16 ? 2 : 4; }
+
+extern "C" int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, mcg_dtype dt) {
+  MCG_CHECK_ARG(out && w, "mcg_engine_create: null pointer");
+  MCG_CHECK_ARG(dt == MCG_F32 || dt == MCG_BF16, "mcg_engine_create: unknown dtype %d", (int)dt);
+  int expect = 0;
+  for (int l = 0; l < 4; ++l) {
+    MCG_CHECK_ARG(w->blocks[l] > 0, "mcg_engine_create: blocks[%d]=%d", l, w->blocks[l]);
+    expect += 3 * w->blocks[l] + 1;
+  }
+  MCG_CHECK_ARG(w->num_convs == expect && w->convs, "mcg_engine_create: expected %d bottleneck convs, got %d", expect, w->num_convs);
+  MCG_CHECK_ARG(w->num_stages > 0 && w->stage_weights && w->gaze_weights && w->init_boxes && w->init_feats, "mcg_engine_create: decoder tables missing");
+  mcg_engine* e = new mcg_engine();
+  e->dt = dt;
+  memcpy(e->blocks, w->blocks, sizeof(e->blocks));
+  e->stem = w->stem;
+  e->convs.assign(w->convs, w->convs + w->num_convs);
+  memcpy(e->lateral, w->lateral, sizeof(e->lateral));
+  memcpy(e->fpn_out, w->fpn_out, sizeof(e->fpn_out));
+  e->init_boxes = w->init_boxes;
+  e->init_feats = w->init_feats;
+  e->num_stages = w->num_stages;
+  e->stage_w.assign(w->stage_weights, w->stage_weights + (size_t)w->num_stages * MCG_SW_COUNT);
+  memcpy(e->gaze_w, w->gaze_weights, sizeof(e->gaze_w));
+  memcpy(e->stds, w->bbox_stds, sizeof(e->stds));
+  for (size_t i = 0; i < e->convs.size(); ++i)
+    if (!e->convs[i].w || !e->convs[i].bias) {
+      delete e;
+      mcg_set_error("mcg_engine_create: conv %zu has a null pointer", i);
+      return MCG_ERR_ARG;
+    }
+  *out = e;
+  return MCG_OK;
+}
+extern "C" void mcg_engine_destroy(mcg_engine* e) { delete e; }
+
+// ---------------------------------------------------------------- trunk workspace for one chunk of n frames
+struct TrunkWs {
+  char *stem_ws, *x0, *xa, *xb, *o1, *o2, *ds, *c[4], *l[4];
+  size_t stem_bytes, total;
+};
+static TrunkWs trunk_layout(mcg_dtype dt, int n, int H, int W, char* base) {
+  const size_t es = esize(dt);
+  const size_t h2 = H / 4, w2 = W / 4;
+  TrunkWs t;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
+  t.stem_bytes = mcg_stem_workspace_bytes(dt, n, H, W);
+  t.stem_ws = take(t.stem_bytes);
+  const size_t big = (size_t)n * h2 * w2 * 256 * es;  // the largest activation: C2 = [n, H/4, W/4, 256]
+  t.x0 = take((size_t)n * h2 * w2 * 64 * es);
+  t.xa = take(big); t.xb = take(big);
+  t.o1 = take(big / 2); t.o2 = take(big / 2);
+  t.ds = take(big);
+  for (int i = 0; i < 4; ++i) {
+    const size_t hi = (H / 4) >> i, wi = (W / 4) >> i;
+    t.c[i] = take((size_t)n * hi * wi * (256u << i) * es);
+    t.l[i] = take((size_t)n * hi * wi * 256 * es);
+  }
+  t.total = off;
+  return t;
+}
+
+static int conv_call(hipStream_t s, mcg_dtype dt, const mcg_conv_weights& cw, const void* x, int n, int h, int w, void* y,
+                     int relu, const void* res, int res_mode, int hr, int wr) {
+  mcg_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.x = x; d.w = cw.w; d.bias = cw.bias; d.residual = res; d.y = y;
+  d.N = n; d.H = h; d.W = w; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.k; d.KW = cw.k; d.stride = cw.stride; d.pad = cw.pad;
+  d.relu = relu; d.residual_mode = res_mode; d.Hr = hr; d.Wr = wr;
+  return mcg_conv2d(s, dt, &d);
+}
+
+// Backbone + FPN over frames [f0, f0+n): writes pyramid level i at frame offset f0.
+static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, int n, int H, int W, void* const pyr[4], char* wsbase) {
+  const mcg_dtype dt = e->dt;
+  const size_t es = esize(dt);
+  TrunkWs t = trunk_layout(dt, n, H, W, wsbase);
+  MCG_TRY(mcg_stem_forward(s, dt, img + (size_t)f0 * 3 * H * W, e->stem.w, e->stem.bias, t.x0, n, H, W, t.stem_ws, t.stem_bytes));
+  const void* x = t.x0;
+  int h = H / 4, w = W / 4, ci = 0;
+  for (int l = 0; l < 4; ++l) {
+    for (int b = 0; b < e->blocks[l]; ++b) {
+      const mcg_conv_weights& c1 = e->convs[ci], &c2 = e->convs[ci + 1], &c3 = e->convs[ci + 2];
+      const bool has_ds = b == 0;
+      const int ho = (h + 2 * c2.pad - c2.k) / c2.stride + 1, wo = (w + 2 * c2.pad - c2.k) / c2.stride + 1;
+      MCG_TRY(conv_call(s, dt, c1, x, n, h, w, t.o1, 1, nullptr, MCG_RES_NONE, 0, 0));
+      MCG_TRY(conv_call(s, dt, c2, t.o1, n, h, w, t.o2, 1, nullptr, MCG_RES_NONE, 0, 0));
+      const void* identity = x;
+      if (has_ds) {
+        MCG_TRY(conv_call(s, dt, e->convs[ci + 3], x, n, h, w, t.ds, 0, nullptr, MCG_RES_NONE, 0, 0));
+        identity = t.ds;
+      }
+      void* y = (b == e->blocks[l] - 1) ? (void*)t.c[l] : (x == t.xa ? (void*)t.xb : (void*)t.xa);
+      MCG_TRY(conv_call(s, dt, c3, t.o2, n, ho, wo, y, 1, identity, MCG_RES_ADD, 0, 0));
+      x = y; h = ho; w = wo;
+      ci += has_ds ? 4 : 3;
+    }
+  }
+  // FPN (fpn.py:157-180): laterals top-down with the nearest-upsample add fused into the epilogue
+  int hs[4], wsz[4];
+  for (int i = 0; i < 4; ++i) { hs[i] = (H / 4) >> i; wsz[i] = (W / 4) >> i; }
+  for (int i = 3; i >= 0; --i) {
+    const void* res = i == 3 ? nullptr : t.l[i + 1];
+    MCG_TRY(conv_call(s, dt, e->lateral[i], t.c[i], n, hs[i], wsz[i], t.l[i], 0, res, res ? MCG_RES_UPSAMPLE_ADD : MCG_RES_NONE,
+                      i == 3 ? 0 : hs[i + 1], i == 3 ? 0 : wsz[i + 1]));
+  }
+  for (int i = 0; i < 4; ++i) {
+    char* dst = (char*)pyr[i] + (size_t)f0 * hs[i] * wsz[i] * 256 * es;
+    MCG_TRY(conv_call(s, dt, e->fpn_out[i], t.l[i], n, hs[i], wsz[i], dst, 0, nullptr, MCG_RES_NONE, 0, 0));
+  }
+  return MCG_OK;
+}
+
+struct ClipWs {
+  char* pyr[4];
+  char *roi, *obj_a, *obj_b, *stage_ws, *gaze_ws, *trunk_ws;
+  float *boxes_a, *boxes_b, *cls;
+  size_t stage_bytes, gaze_bytes, trunk_bytes, total;
+};
+static ClipWs clip_layout(mcg_dtype dt, int N, int H, int W, int chunk, bool with_decoder, char* base) {
+  const size_t es = esize(dt);
+  ClipWs c;
+  memset(&c, 0, sizeof(c));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
+  if (chunk <= 0 || chunk > N) chunk = N;
+  c.trunk_bytes = trunk_layout(dt, chunk, H, W, nullptr).total;
+  c.trunk_ws = take(c.trunk_bytes);
+  if (with_decoder) {
+    for (int i = 0; i < 4; ++i) c.pyr[i] = take((size_t)N * ((H / 4) >> i) * ((W / 4) >> i) * 256 * es);
+    const size_t R = (size_t)N * 3;
+    c.roi = take(R * 49 * 256 * es);
+    c.obj_a = take(R * 256 * es); c.obj_b = take(R * 256 * es);
+    c.boxes_a = (float*)take(R * 4 * 4); c.boxes_b = (float*)take(R * 4 * 4); c.cls = (float*)take(R * 4);
+    c.stage_bytes = mcg_stage_workspace_bytes(dt, N); c.stage_ws = take(c.stage_bytes);
+    c.gaze_bytes = mcg_gaze_head_workspace_bytes(dt, N); c.gaze_ws = take(c.gaze_bytes);
+  }
+  c.total = off;
+  return c;
+}
+
+extern "C" size_t mcg_engine_workspace_bytes(const mcg_engine* e, int N, int H, int W, int chunk) {
+  if (!e || N <= 0) return 0;
+  return clip_layout(e->dt, N, H, W, chunk, true, nullptr).total;
+}
+
+static int check_shape(int N, int H, int W) {
+  MCG_CHECK_ARG(N > 0, "num_frames must be positive (got %d)", N);
+  MCG_CHECK_ARG(H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0, "frame size %dx%d must be a multiple of 32 (Pad(size_divisor=32))", H, W);
+  return MCG_OK;
+}
+
+extern "C" int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s_, const float* img, int N, int H, int W, int chunk,
+                                        void* const pyramid[4], void* ws, size_t ws_bytes) {
+  MCG_CHECK_ARG(e && img && pyramid && ws, "mcg_backbone_fpn_forward: null pointer");
+  MCG_TRY(check_shape(N, H, W));
+  if (chunk <= 0 || chunk > N) chunk = N;
+  const size_t need = trunk_layout(e->dt, chunk, H, W, nullptr).total;
+  if (ws_bytes < need) { mcg_set_error("mcg_backbone_fpn_forward: workspace too small (%zu < %zu)", ws_bytes, need); return MCG_ERR_WORKSPACE; }
+  for (int f0 = 0; f0 < N; f0 += chunk) MCG_TRY(trunk_chunk(e, (hipStream_t)s_, img, f0, (N - f0) < chunk ? (N - f0) : chunk, H, W, pyramid, (char*)ws));
+  return MCG_OK;
+}
+
+extern "C" int mcg_clip_forward(mcg_engine* e, mcg_stream s_, const float* img, int N, int clip_length, int H, int W,
+                                const int* img_hw, int chunk, float* gaze_out, float* boxes_out, float* scores_out,
+                                void* ws, size_t ws_bytes) {
+  hipStream_t s = (hipStream_t)s_;
+  MCG_CHECK_ARG(e && img && gaze_out && boxes_out && scores_out && ws, "mcg_clip_forward: null pointer");
+  MCG_TRY(check_shape(N, H, W));
+  MCG_CHECK_ARG(clip_length > 0 && N % clip_length == 0, "mcg_clip_forward: num_frames=%d is not a multiple of clip_length=%d", N, clip_length);
+  if (chunk <= 0 || chunk > N) chunk = N;
+  ClipWs c = clip_layout(e->dt, N, H, W, chunk, true, (char*)ws);
+  if (ws_bytes < c.total) { mcg_set_error("mcg_clip_forward: workspace too small (%zu < %zu)", ws_bytes, c.total); return MCG_ERR_WORKSPACE; }
+  void* pyr[4] = {c.pyr[0], c.pyr[1], c.pyr[2], c.pyr[3]};
+  for (int f0 = 0; f0 < N; f0 += chunk) MCG_TRY(trunk_chunk(e, s, img, f0, (N - f0) < chunk ? (N - f0) : chunk, H, W, pyr, c.trunk_ws));
+  MCG_TRY(launch_init_queries(s, e->dt, e->init_boxes, e->init_feats, img_hw, H, W, c.boxes_a, c.obj_a, N));
+  int fh[4], fw[4];
+  const int strides[4] = {4, 8, 16, 32};
+  for (int i = 0; i < 4; ++i) { fh[i] = (H / 4) >> i; fw[i] = (W / 4) >> i; }
+  char* obj_in = c.obj_a; char* obj_out = c.obj_b;
+  float* b_in = c.boxes_a; float* b_out = c.boxes_b;
+  for (int st = 0; st < e->num_stages; ++st) {
+    MCG_TRY(launch_roi_align(s, e->dt, pyr, fh, fw, strides, 256, b_in, N * 3, 3, c.roi, nullptr));
+    float* bdst = (st == e->num_stages - 1) ? boxes_out : b_out;
+    MCG_TRY(mcg_stage_forward(s, e->dt, &e->stage_w[(size_t)st * MCG_SW_COUNT], c.roi, obj_in, b_in, N, clip_length, obj_out, bdst,
+                              c.cls, e->stds, c.stage_ws, c.stage_bytes));
+    char* t = obj_in; obj_in = obj_out; obj_out = t;
+    if (st != e->num_stages - 1) { float* tb = b_in; b_in = b_out; b_out = tb; }
+  }
+  MCG_TRY(launch_sigmoid(s, c.cls, scores_out, N * 3));
+  MCG_TRY(mcg_gaze_head(s, e->dt, e->gaze_w, obj_in, N, gaze_out, c.gaze_ws, c.gaze_bytes));
+  return MCG_OK;
+}

@@ -1,0 +1,270 @@
+// Host launchers for the implicit-GEMM kernel + the trunk's memory-bound helpers
+// (stem input packing, 3x3/s2 max-pool, NCHW<->NHWC).
+#include "igemm.hpp"
+
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+void mcg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* mcg_last_error(void) { return g_err; }
+extern "C" int mcg_abi_version(void) { return MCG_ABI_VERSION; }
+extern "C" int mcg_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    mcg_set_error("mcg_device_info: no HIP device");
+    return MCG_ERR_HIP;
+  }
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  if (arch && arch_len > 0) {
+    strncpy(arch, prop.gcnArchName, arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return MCG_OK;
+}
+
+template <typename T, int BM, int BN, int BKB, int WM, int WN>
+static void launch_cfg(hipStream_t s, const IgemmParams& p, int groups) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+  dim3 grid(tiles, p.splitk, groups);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, BKB, WM, WN>), grid, dim3(256), 0, s, p);
+}
+
+template <typename T>
+static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
+  constexpr int ES = (int)sizeof(T);
+  // K-slice width: 128 bytes of K per row when the tap vector allows it, else 64.
+  const bool wide = (p.Cin * ES) % 128 == 0;
+  MCG_CHECK_ARG((p.Cin * ES) % 64 == 0, "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
+  MCG_CHECK_ARG(p.Cout % (16 / ES) == 0, "igemm: Cout=%d must be a multiple of %d", p.Cout, 16 / ES);
+  if (p.Cout <= 64) {
+    if (wide) launch_cfg<T, 128, 64, 128, 4, 1>(s, p, groups);
+    else launch_cfg<T, 128, 64, 64, 4, 1>(s, p, groups);
+  } else {
+    if (wide) launch_cfg<T, 128, 128, 128, 2, 2>(s, p, groups);
+    else launch_cfg<T, 128, 128, 64, 2, 2>(s, p, groups);
+  }
+  MCG_CHECK_LAUNCH("igemm launch");
+  return MCG_OK;
+}
+
+int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p, int groups) {
+  MCG_CHECK_ARG(p.M > 0 && p.Cout > 0 && groups > 0, "igemm: empty problem (M=%d Cout=%d groups=%d)", p.M, p.Cout, groups);
+  return dt == MCG_BF16 ? launch_typed<bf16_t>(s, p, groups) : launch_typed<float>(s, p, groups);
+}
+
+static IgemmParams linear_params(const void* x, long long lda, const void* w, int M, int K, int Cout) {
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.w = w;
+  p.M = M; p.Ho = 1; p.Wo = 1; p.H = 1; p.W = 1; p.Cin = K; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.Cout = Cout;
+  p.xs_n = lda; p.xs_h = 0; p.xs_w = 0; p.nocheck = 1;
+  p.splitk = 1; p.tiles_per_slice = 1 << 30;
+  return p;
+}
+
+int launch_linear(hipStream_t s, mcg_dtype dt, const void* x, long long lda, const void* w, const float* bias,
+                  const void* res, long long ldres, void* y, long long ldy, int M, int K, int Cout, int relu) {
+  IgemmParams p = linear_params(x, lda, w, M, K, Cout);
+  p.bias = bias; p.res = res; p.y = y;
+  p.y_row_stride = ldy; p.res_row_stride = ldres;
+  p.relu = relu; p.res_mode = res ? MCG_RES_ADD : MCG_RES_NONE;
+  return launch_igemm(s, dt, p, 1);
+}
+
+int launch_linear_splitk(hipStream_t s, mcg_dtype dt, const void* x, long long lda, const void* w, float* partial,
+                         int M, int K, int Cout, int want_slices, int* splitk_out) {
+  IgemmParams p = linear_params(x, lda, w, M, K, Cout);
+  const int es = dt == MCG_BF16 ? 2 : 4;
+  const int bk = (((long long)K * es) % 128 == 0 ? 128 : 64) / es;
+  const int KT = K / bk;
+  int slices = want_slices < 1 ? 1 : (want_slices > KT ? KT : want_slices);
+  const int per = (KT + slices - 1) / slices;
+  slices = (KT + per - 1) / per;
+  p.partial = partial;
+  p.splitk = slices; p.tiles_per_slice = per;
+  if (slices == 1) p.splitk = 2;  // force the slab path; slice 1 is empty and writes zeros
+  *splitk_out = p.splitk;
+  return launch_igemm(s, dt, p, 1);
+}
+
+extern "C" int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d) {
+  MCG_CHECK_ARG(d && d->x && d->w && d->y, "mcg_conv2d: null pointer");
+  MCG_CHECK_ARG(d->stride >= 1 && d->KH >= 1 && d->KW >= 1, "mcg_conv2d: bad geometry");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = d->x; p.w = d->w; p.bias = d->bias; p.res = d->residual; p.y = d->y;
+  p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.Cout = d->Cout;
+  p.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+  p.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+  MCG_CHECK_ARG(p.Ho > 0 && p.Wo > 0, "mcg_conv2d: empty output");
+  p.M = d->N * p.Ho * p.Wo;
+  p.xs_w = d->Cin; p.xs_h = (long long)d->W * d->Cin; p.xs_n = (long long)d->H * d->W * d->Cin;
+  p.y_row_stride = d->Cout; p.res_row_stride = d->Cout;
+  p.relu = d->relu; p.res_mode = d->residual ? d->residual_mode : MCG_RES_NONE;
+  if (p.res_mode == MCG_RES_UPSAMPLE_ADD) {
+    MCG_CHECK_ARG(d->Hr > 0 && d->Wr > 0, "mcg_conv2d: UPSAMPLE_ADD needs Hr, Wr");
+    p.Hr = d->Hr; p.Wr = d->Wr;
+    p.rscale_h = (float)d->Hr / (float)p.Ho;  // torch nearest: src = min(floor(dst * in/out), in-1)
+    p.rscale_w = (float)d->Wr / (float)p.Wo;
+  }
+  p.splitk = 1; p.tiles_per_slice = 1 << 30;
+  return launch_igemm((hipStream_t)s, dt, p, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem.  The 7x7/s2 conv over 3 channels is run by the same implicit-GEMM kernel: the NCHW f32
+// frame is first repacked to a zero-bordered NHWC4 image [N][H+6][W+8][4]; one "tap" is then a
+// whole kernel row = 8 pixels x 4 channels = 32 contiguous elements (kw=7 and c=3 carry zero
+// weights), so K = 7 taps x 32 and no bounds checks are needed.
+template <typename T>
+__global__ void stem_pack_kernel(const float* __restrict__ img, T* __restrict__ dst, int N, int H, int W, int Hp, int Wp) {
+  const long long total = (long long)N * Hp * Wp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int wp = (int)(i % Wp);
+    const long long t = i / Wp;
+    const int hp = (int)(t % Hp), n = (int)(t / Hp);
+    const int h = hp - 3, w = wp - 3;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+      const float* src = img + ((long long)n * 3 * H + h) * W + w;
+      v0 = src[0]; v1 = src[(long long)H * W]; v2 = src[2LL * H * W];
+    }
+    T* o = dst + i * 4;
+    Elem<T>::st(o, v0); Elem<T>::st(o + 1, v1); Elem<T>::st(o + 2, v2); Elem<T>::st(o + 3, 0.f);
+  }
+}
+
+// max-pool 3x3 stride 2 pad 1 over NHWC (resnet.py:611); one thread per 16-byte channel chunk.
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+  constexpr int EPC = Elem<T>::kPerChunk;
+  const int cchunks = C / EPC;
+  const long long total = (long long)N * Ho * Wo * cchunks;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long long t = i / cchunks;
+    const int wo = (int)(t % Wo); t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float m[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int h = ho * 2 - 1 + dy;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int w = wo * 2 - 1 + dx;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float v[EPC];
+        chunk_to_f32(*(const uint4*)(x + (((long long)n * H + h) * W + w) * C + cc * EPC), v, (T*)nullptr);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+    *(uint4*)(y + i * EPC) = f32_to_chunk(m, (T*)nullptr);
+  }
+}
+
+static inline int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  return (int)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
+}
+
+extern "C" size_t mcg_stem_workspace_bytes(mcg_dtype dt, int N, int H, int W) {
+  const size_t es = dt == MCG_BF16 ? 2 : 4;
+  const size_t packed = (size_t)N * (H + 6) * (W + 8) * 4 * es;
+  const size_t conv = (size_t)N * (H / 2) * (W / 2) * 64 * es;
+  return ((packed + 255) / 256) * 256 + ((conv + 255) / 256) * 256;
+}
+
+extern "C" int mcg_stem_forward(mcg_stream s_, mcg_dtype dt, const float* img, const void* w_stem, const float* bias,
+                                void* y, int N, int H, int W, void* ws, size_t ws_bytes) {
+  hipStream_t s = (hipStream_t)s_;
+  MCG_CHECK_ARG(img && w_stem && y && ws, "mcg_stem_forward: null pointer");
+  MCG_CHECK_ARG(H % 4 == 0 && W % 4 == 0, "mcg_stem_forward: H, W must be multiples of 4 (got %dx%d)", H, W);
+  if (ws_bytes < mcg_stem_workspace_bytes(dt, N, H, W)) {
+    mcg_set_error("mcg_stem_forward: workspace too small (%zu < %zu)", ws_bytes, mcg_stem_workspace_bytes(dt, N, H, W));
+    return MCG_ERR_WORKSPACE;
+  }
+  const size_t es = dt == MCG_BF16 ? 2 : 4;
+  const int Hp = H + 6, Wp = W + 8, Hc = H / 2, Wc = W / 2;
+  char* packed = (char*)ws;
+  char* conv = packed + (((size_t)N * Hp * Wp * 4 * es + 255) / 256) * 256;
+  const long long npix = (long long)N * Hp * Wp;
+  if (dt == MCG_BF16) hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, s, img, (bf16_t*)packed, N, H, W, Hp, Wp);
+  else hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, s, img, (float*)packed, N, H, W, Hp, Wp);
+  MCG_CHECK_LAUNCH("stem_pack");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = packed; p.w = w_stem; p.bias = bias; p.y = conv;
+  p.Ho = Hc; p.Wo = Wc; p.M = N * Hc * Wc; p.H = Hp; p.W = Wp; p.Cin = 32; p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 0; p.Cout = 64;
+  p.xs_w = 4; p.xs_h = (long long)Wp * 4; p.xs_n = (long long)Hp * Wp * 4; p.nocheck = 1;
+  p.y_row_stride = 64; p.relu = 1; p.res_mode = MCG_RES_NONE; p.splitk = 1; p.tiles_per_slice = 1 << 30;
+  MCG_TRY(launch_igemm(s, dt, p, 1));
+  const int Ho = (Hc + 2 - 3) / 2 + 1, Wo = (Wc + 2 - 3) / 2 + 1;
+  const long long nchunks = (long long)N * Ho * Wo * (64 / (16 / (int)es));
+  if (dt == MCG_BF16) hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(grid_for(nchunks, 256)), dim3(256), 0, s, (const bf16_t*)conv, (bf16_t*)y, N, Hc, Wc, 64, Ho, Wo);
+  else hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(nchunks, 256)), dim3(256), 0, s, (const float*)conv, (float*)y, N, Hc, Wc, 64, Ho, Wo);
+  MCG_CHECK_LAUNCH("maxpool");
+  return MCG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layout conversion through an LDS tile so both sides stay coalesced.
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int HW) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, pix = p0 + tx;
+    tile[j][tx] = (c < C && pix < HW) ? src[((long long)n * C + c) * HW + pix] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int pix = p0 + j, c = c0 + tx;
+    if (c < C && pix < HW) Elem<T>::st(dst + ((long long)n * HW + pix) * C + c, tile[tx][j]);
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C, int HW) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int pix = p0 + j, c = c0 + tx;
+    tile[j][tx] = (c < C && pix < HW) ? Elem<T>::ld(src + ((long long)n * HW + pix) * C + c) : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, pix = p0 + tx;
+    if (c < C && pix < HW) dst[((long long)n * C + c) * HW + pix] = tile[tx][j];
+  }
+}
+
+extern "C" int mcg_nchw_to_nhwc(mcg_stream s, mcg_dtype dt, const float* src, void* dst, int N, int C, int H, int W) {
+  MCG_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "mcg_nchw_to_nhwc: bad argument");
+  dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
+  if (dt == MCG_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, src, (bf16_t*)dst, C, H * W);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, src, (float*)dst, C, H * W);
+  MCG_CHECK_LAUNCH("nchw_to_nhwc");
+  return MCG_OK;
+}
+extern "C" int mcg_nhwc_to_nchw(mcg_stream s, mcg_dtype dt, const void* src, float* dst, int N, int C, int H, int W) {
+  MCG_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "mcg_nhwc_to_nchw: bad argument");
+  dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
+  if (dt == MCG_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)src, dst, C, H * W);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)src, dst, C, H * W);
+  MCG_CHECK_LAUNCH("nhwc_to_nchw");
+  return MCG_OK;
+}

@@ -1,0 +1,214 @@
+"""Host-side driver of ``libmcgaze_hip.so``: owns the packed weights, the workspace and the
+C engine handle, and exposes the path (and its individual operators, for the parity tests)
+over torch device tensors.  PyTorch is used for device memory and streams only; all
+arithmetic runs in the hand-written HIP kernels behind the C-ABI.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .packing import PackedWeights
+
+_TORCH_DT = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32}
+
+
+def _code(dtype):
+    return L.MCG_BF16 if dtype == torch.bfloat16 else L.MCG_F32
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise L.McgError('mcgaze_amd needs a HIP device (MI355X / gfx950); there is no CPU fallback path')
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------ operators
+def to_nhwc(x_nchw, dtype):
+    """[N,C,H,W] f32 device tensor -> NHWC ``dtype`` via mcg_nchw_to_nhwc."""
+    _require_gpu()
+    lib = L.load()
+    N, Cc, H, W = x_nchw.shape
+    x = x_nchw.contiguous().float()
+    out = torch.empty(N, H, W, Cc, dtype=dtype, device=x.device)
+    L.check(lib.mcg_nchw_to_nhwc(_stream(), _code(dtype), _ptr(x), _ptr(out), N, Cc, H, W), 'mcg_nchw_to_nhwc')
+    return out
+
+
+def to_nchw(x_nhwc):
+    _require_gpu()
+    lib = L.load()
+    N, H, W, Cc = x_nhwc.shape
+    out = torch.empty(N, Cc, H, W, dtype=torch.float32, device=x_nhwc.device)
+    L.check(lib.mcg_nhwc_to_nchw(_stream(), _code(x_nhwc.dtype), _ptr(x_nhwc.contiguous()), _ptr(out), N, Cc, H, W), 'mcg_nhwc_to_nchw')
+    return out
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual_mode=L.RES_NONE):
+    """x NHWC, w OHWI (same dtype), bias f32 -> NHWC.  mcg_conv2d."""
+    _require_gpu()
+    lib = L.load()
+    N, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    y = torch.empty(N, Ho, Wo, Cout, dtype=x.dtype, device=x.device)
+    d = L.ConvDesc(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                   residual.data_ptr() if residual is not None else None, y.data_ptr(),
+                   N, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), residual_mode if residual is not None else L.RES_NONE,
+                   residual.shape[1] if residual is not None else 0, residual.shape[2] if residual is not None else 0)
+    L.check(lib.mcg_conv2d(_stream(), _code(x.dtype), C.byref(d)), 'mcg_conv2d')
+    return y
+
+
+def stem(img, w_stem, bias, dtype):
+    """img [N,3,H,W] f32 -> [N,H/4,W/4,64] NHWC.  mcg_stem_forward."""
+    _require_gpu()
+    lib = L.load()
+    N, _, H, W = img.shape
+    ws = _ws(lib.mcg_stem_workspace_bytes(_code(dtype), N, H, W), img.device)
+    y = torch.empty(N, H // 4, W // 4, 64, dtype=dtype, device=img.device)
+    L.check(lib.mcg_stem_forward(_stream(), _code(dtype), _ptr(img.contiguous()), _ptr(w_stem), _ptr(bias), _ptr(y), N, H, W,
+                                 _ptr(ws), ws.numel()), 'mcg_stem_forward')
+    return y
+
+
+def roi_align(feats, boxes, strides=(4, 8, 16, 32)):
+    """feats: 4 NHWC levels; boxes [N,P,4] f32 -> ([N*P,49,C], levels int32 [N*P]).  mcg_roi_align."""
+    _require_gpu()
+    lib = L.load()
+    N, P = boxes.shape[:2]
+    Cc = feats[0].shape[-1]
+    out = torch.empty(N * P, 49, Cc, dtype=feats[0].dtype, device=boxes.device)
+    lv = torch.empty(N * P, dtype=torch.int32, device=boxes.device)
+    fp = (C.c_void_p * 4)(*[f.data_ptr() for f in feats])
+    fh = (C.c_int * 4)(*[f.shape[1] for f in feats])
+    fw = (C.c_int * 4)(*[f.shape[2] for f in feats])
+    st = (C.c_int * 4)(*strides)
+    b = boxes.contiguous().float()
+    L.check(lib.mcg_roi_align(_stream(), _code(feats[0].dtype), fp, fh, fw, st, Cc, _ptr(b), N * P, P, _ptr(out), _ptr(lv)), 'mcg_roi_align')
+    return out, lv
+
+
+def _table(d, keys):
+    return (C.c_void_p * len(keys))(*[d[k].data_ptr() for k in keys])
+
+
+def stage_forward(stage_w, roi_feat, obj, boxes, clip_length, stds=(0.5, 0.5, 1.0, 1.0)):
+    """One decoder stage.  roi_feat [R,49,256], obj [N,3,256], boxes [N,3,4] f32
+    -> (obj' [N,3,256], boxes' [N,3,4], cls logits [N,3]).  mcg_stage_forward."""
+    _require_gpu()
+    lib = L.load()
+    N = obj.shape[0]
+    dt = _code(obj.dtype)
+    ws = _ws(lib.mcg_stage_workspace_bytes(dt, N), obj.device)
+    obj_out = torch.empty_like(obj)
+    boxes_out = torch.empty(N, 3, 4, dtype=torch.float32, device=obj.device)
+    cls = torch.empty(N, 3, dtype=torch.float32, device=obj.device)
+    sd = (C.c_float * 4)(*stds)
+    L.check(lib.mcg_stage_forward(_stream(), dt, _table(stage_w, L.STAGE_KEYS), _ptr(roi_feat.contiguous()), _ptr(obj.contiguous()),
+                                  _ptr(boxes.contiguous().float()), N, clip_length, _ptr(obj_out), _ptr(boxes_out), _ptr(cls), sd,
+                                  _ptr(ws), ws.numel()), 'mcg_stage_forward')
+    return obj_out, boxes_out, cls
+
+
+def gaze_head(gaze_w, obj):
+    """obj [N,3,256] -> [4,N,3] f32 unit vectors (fused, face, eyes, head).  mcg_gaze_head."""
+    _require_gpu()
+    lib = L.load()
+    N = obj.shape[0]
+    dt = _code(obj.dtype)
+    ws = _ws(lib.mcg_gaze_head_workspace_bytes(dt, N), obj.device)
+    out = torch.empty(4, N, 3, dtype=torch.float32, device=obj.device)
+    L.check(lib.mcg_gaze_head(_stream(), dt, _table(gaze_w, L.GAZE_KEYS), _ptr(obj.contiguous()), N, _ptr(out), _ptr(ws), ws.numel()), 'mcg_gaze_head')
+    return out
+
+
+# ------------------------------------------------------------------------------------ engine
+class HipEngine:
+    """The whole per-clip forward path behind one C call (mcg_clip_forward)."""
+
+    def __init__(self, state_dict, depth=50, num_stages=4, precision='bf16', device='cuda:0', bbox_stds=(0.5, 0.5, 1.0, 1.0)):
+        _require_gpu()
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.dtype = _TORCH_DT[precision]
+        self.precision = precision
+        self.weights = PackedWeights(state_dict, depth=depth, num_stages=num_stages, dtype=self.dtype, device=self.device)
+        w = self.weights
+        mk = lambda c: L.ConvWeights(c['w'].data_ptr(), c['bias'].data_ptr(), c['cin'], c['cout'], c['k'], c['stride'], c['pad'])
+        self._convs = (L.ConvWeights * len(w.convs))(*[mk(c) for c in w.convs])
+        self._stage_tab = (C.c_void_p * (num_stages * L.SW_COUNT))(*[st[k].data_ptr() for st in w.stages for k in L.STAGE_KEYS])
+        self._gaze_tab = _table(w.gaze, L.GAZE_KEYS)
+        mw = L.ModelWeights()
+        mw.blocks = (C.c_int * 4)(*w.blocks)
+        mw.stem = mk(w.stem)
+        mw.convs = C.cast(self._convs, C.POINTER(L.ConvWeights))
+        mw.num_convs = len(w.convs)
+        mw.lateral = (L.ConvWeights * 4)(*[mk(c) for c in w.lateral])
+        mw.fpn_out = (L.ConvWeights * 4)(*[mk(c) for c in w.fpn_out])
+        mw.init_boxes = w.init_boxes.data_ptr()
+        mw.init_feats = w.init_feats.data_ptr()
+        mw.num_stages = num_stages
+        mw.stage_weights = C.cast(self._stage_tab, C.POINTER(C.c_void_p))
+        mw.gaze_weights = C.cast(self._gaze_tab, C.POINTER(C.c_void_p))
+        mw.bbox_stds = (C.c_float * 4)(*bbox_stds)
+        self._handle = C.c_void_p()
+        L.check(self.lib.mcg_engine_create(C.byref(self._handle), C.byref(mw), _code(self.dtype)), 'mcg_engine_create')
+        self._ws = None
+        self._ws_key = None
+
+    def __del__(self):
+        h = getattr(self, '_handle', None)
+        if h is not None and h.value:
+            self.lib.mcg_engine_destroy(h)
+            self._handle = None
+
+    def _workspace(self, N, H, W, chunk):
+        key = (N, H, W, chunk)
+        need = self.lib.mcg_engine_workspace_bytes(self._handle, N, H, W, chunk)
+        if self._ws is None or self._ws.numel() < need or self._ws_key != key:
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = _ws(need, self.device)
+            self._ws_key = key
+        return self._ws
+
+    def backbone_fpn(self, img, chunk_frames=0):
+        """img [N,3,H,W] f32 on the device -> [P2..P5] NHWC in the engine dtype."""
+        N, _, H, W = img.shape
+        ws = self._workspace(N, H, W, chunk_frames)
+        pyr = [torch.empty(N, (H // 4) >> i, (W // 4) >> i, 256, dtype=self.dtype, device=self.device) for i in range(4)]
+        tab = (C.c_void_p * 4)(*[p.data_ptr() for p in pyr])
+        L.check(self.lib.mcg_backbone_fpn_forward(self._handle, _stream(), _ptr(img), N, H, W, chunk_frames, tab, _ptr(ws), ws.numel()),
+                'mcg_backbone_fpn_forward')
+        return pyr
+
+    def forward(self, img, clip_length, img_hw=None, chunk_frames=0, out=None):
+        """img [N,3,H,W] f32 (device, contiguous), N = clips*clip_length.
+        Returns dict(gaze [4,N,3], boxes [N,3,4], scores [N,3]) -- f32 device tensors."""
+        assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+        N, _, H, W = img.shape
+        ws = self._workspace(N, H, W, chunk_frames)
+        if out is None:
+            out = dict(gaze=torch.empty(4, N, 3, dtype=torch.float32, device=self.device),
+                       boxes=torch.empty(N, 3, 4, dtype=torch.float32, device=self.device),
+                       scores=torch.empty(N, 3, dtype=torch.float32, device=self.device))
+        hw = None
+        if img_hw is not None:
+            hw = torch.as_tensor(np.asarray(img_hw, dtype=np.int32).reshape(N, 2)).to(self.device) if not isinstance(img_hw, torch.Tensor) else img_hw
+        L.check(self.lib.mcg_clip_forward(self._handle, _stream(), _ptr(img), N, clip_length, H, W, _ptr(hw), chunk_frames,
+                                          _ptr(out['gaze']), _ptr(out['boxes']), _ptr(out['scores']), _ptr(ws), ws.numel()),
+                'mcg_clip_forward')
+        return out

@@ -1,0 +1,140 @@
+"""Checkpoint -> kernel-ready weights (load time, not the hot path).
+
+Takes the reference's ``state_dict`` layout (the dead ``fc_cls`` /
+``fc_reg`` and the unused ``gaze_head.0-2`` are tolerated and ignored) and produces the
+buffers ``libmcgaze_hip.so`` expects (``include/mcgaze_hip.h``):
+
+* BN folded into the preceding conv: ``w' = w * g/sqrt(var+eps)``, ``b' = beta - mean*g/sqrt(var+eps)``
+  (eval-mode BN, resnet.py:648-658), computed in float64;
+* conv weights OIHW -> OHWI (K = (kh, kw, cin) contiguous) in the compute dtype;
+* stem 7x7x3 -> [64][7][8][4] (kw and channel zero-padded: one kernel row is one 32-element tap);
+* ``dynamic_layer`` rows permuted so the generated 1x1-conv weights come out K-contiguous;
+* per-clue heads and the gaze-head branches stacked into the tables the kernels index.
+"""
+import numpy as np
+import torch
+
+from .synth import ARCH
+
+CLUES = ('face', 'eyes', 'head')
+
+
+def _t(v):
+    return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))
+
+
+def normalize_state_dict(sd):
+    """init_detector's key rewrite (mmdet/apis/inference.py:45): strip ``module.``; accept the
+    mmcv ``{'meta':…, 'state_dict':…}`` envelope."""
+    if 'state_dict' in sd and not any(k.startswith('backbone.') for k in sd):
+        sd = sd['state_dict']
+    out = {}
+    for k, v in sd.items():
+        if k.startswith('module.'):
+            k = k[len('module.'):]
+        out[k] = _t(v)
+    return out
+
+
+def fold_bn(sd, conv_key, bn_prefix, eps=1e-5):
+    w = sd[conv_key].double()
+    g, b = sd[bn_prefix + '.weight'].double(), sd[bn_prefix + '.bias'].double()
+    mean, var = sd[bn_prefix + '.running_mean'].double(), sd[bn_prefix + '.running_var'].double()
+    scale = g / torch.sqrt(var + eps)
+    return (w * scale[:, None, None, None]).float(), (b - mean * scale).float()
+
+
+def ohwi(w):
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def dyn_permutation(d=256, feat=64):
+    """Row permutation of dynamic_layer: new row n*d+k <- old row k*feat+n (param_in^T, [feat][d]);
+    new row d*feat + n*feat+k <- old row d*feat + k*d+n (param_out^T, [d][feat]); transformer.py:1134-1137."""
+    n, k = torch.meshgrid(torch.arange(feat), torch.arange(d), indexing='ij')
+    p_in = (k * feat + n).reshape(-1)
+    n2, k2 = torch.meshgrid(torch.arange(d), torch.arange(feat), indexing='ij')
+    p_out = (d * feat + k2 * d + n2).reshape(-1)
+    return torch.cat([p_in, p_out])
+
+
+class PackedWeights:
+    """Device-resident packed weights + the geometry tables the engine needs."""
+
+    def __init__(self, state_dict, depth=50, num_stages=4, dtype=torch.bfloat16, device='cuda:0'):
+        sd = normalize_state_dict(state_dict)
+        self.dtype, self.device, self.depth, self.num_stages = dtype, torch.device(device), depth, num_stages
+        self.blocks = ARCH[depth]
+        self._keep = []
+        mat = lambda t: self._dev(t.to(dtype))
+        vec = lambda t: self._dev(t.float())
+
+        w, b = fold_bn(sd, 'backbone.conv1.weight', 'backbone.bn1')
+        stem = torch.zeros(64, 7, 8, 4)
+        stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+        self.stem = dict(w=mat(stem), bias=vec(b), cin=32, cout=64, k=7, stride=2, pad=3)
+        self.convs = []
+        for li, nb in enumerate(self.blocks):
+            for bi in range(nb):
+                p = f'backbone.layer{li + 1}.{bi}'
+                stride = 2 if (bi == 0 and li > 0) else 1
+                for conv, bn, k, s, pad in (('conv1', 'bn1', 1, 1, 0), ('conv2', 'bn2', 3, stride, 1), ('conv3', 'bn3', 1, 1, 0)):
+                    w, b = fold_bn(sd, f'{p}.{conv}.weight', f'{p}.{bn}')
+                    self.convs.append(dict(w=mat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=k, stride=s, pad=pad))
+                if f'{p}.downsample.0.weight' in sd:
+                    w, b = fold_bn(sd, f'{p}.downsample.0.weight', f'{p}.downsample.1')
+                    self.convs.append(dict(w=mat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=1, stride=stride, pad=0))
+        self.lateral, self.fpn_out = [], []
+        for i in range(4):
+            w = sd[f'neck.lateral_convs.{i}.conv.weight']
+            self.lateral.append(dict(w=mat(ohwi(w)), bias=vec(sd[f'neck.lateral_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=1, stride=1, pad=0))
+            w = sd[f'neck.fpn_convs.{i}.conv.weight']
+            self.fpn_out.append(dict(w=mat(ohwi(w)), bias=vec(sd[f'neck.fpn_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=3, stride=1, pad=1))
+        self.init_boxes = vec(sd['rpn_head.init_proposal_bboxes.weight'])
+        self.init_feats = mat(sd['rpn_head.init_proposal_features.weight'])
+        perm = dyn_permutation()
+        self.stages = []
+        for s in range(num_stages):
+            p = f'roi_head.bbox_head.{s}'
+            q = p + '.instance_interactive_conv'
+            st = dict(
+                IN_PROJ_W=mat(sd[p + '.attention.attn.in_proj_weight']), IN_PROJ_B=vec(sd[p + '.attention.attn.in_proj_bias']),
+                OUT_PROJ_W=mat(sd[p + '.attention.attn.out_proj.weight']), OUT_PROJ_B=vec(sd[p + '.attention.attn.out_proj.bias']),
+                ATTN_LN_G=vec(sd[p + '.attention_norm.weight']), ATTN_LN_B=vec(sd[p + '.attention_norm.bias']),
+                DYN_W=mat(sd[q + '.dynamic_layer.weight'][perm]), DYN_B=vec(sd[q + '.dynamic_layer.bias'][perm]),
+                NORM_IN_G=vec(sd[q + '.norm_in.weight']), NORM_IN_B=vec(sd[q + '.norm_in.bias']),
+                NORM_OUT_G=vec(sd[q + '.norm_out.weight']), NORM_OUT_B=vec(sd[q + '.norm_out.bias']),
+                FC_W=mat(sd[q + '.fc_layer.weight']), FC_B=vec(sd[q + '.fc_layer.bias']),
+                FC_LN_G=vec(sd[q + '.fc_norm.weight']), FC_LN_B=vec(sd[q + '.fc_norm.bias']),
+                IIC_LN_G=vec(sd[p + '.instance_interactive_conv_norm.weight']), IIC_LN_B=vec(sd[p + '.instance_interactive_conv_norm.bias']),
+                FFN1_W=mat(sd[p + '.ffn.layers.0.0.weight']), FFN1_B=vec(sd[p + '.ffn.layers.0.0.bias']),
+                FFN2_W=mat(sd[p + '.ffn.layers.1.weight']), FFN2_B=vec(sd[p + '.ffn.layers.1.bias']),
+                FFN_LN_G=vec(sd[p + '.ffn_norm.weight']), FFN_LN_B=vec(sd[p + '.ffn_norm.bias']),
+                CLS_FC_W=mat(sd[p + '.cls_fcs.0.weight']), CLS_LN_G=vec(sd[p + '.cls_fcs.1.weight']), CLS_LN_B=vec(sd[p + '.cls_fcs.1.bias']),
+                REG_FC_W=mat(torch.stack([sd[p + f'.reg_fcs.{3 * j}.weight'] for j in range(3)])),
+                REG_LN_G=vec(torch.stack([sd[p + f'.reg_fcs.{3 * j + 1}.weight'] for j in range(3)])),
+                REG_LN_B=vec(torch.stack([sd[p + f'.reg_fcs.{3 * j + 1}.bias'] for j in range(3)])),
+                HEAD_CLS_W=vec(torch.cat([sd[p + f'.{c}_fc_cls.weight'] for c in CLUES])),
+                HEAD_CLS_B=vec(torch.cat([sd[p + f'.{c}_fc_cls.bias'] for c in CLUES])),
+                HEAD_REG_W=vec(torch.stack([sd[p + f'.{c}_fc_reg.weight'] for c in CLUES])),
+                HEAD_REG_B=vec(torch.stack([sd[p + f'.{c}_fc_reg.bias'] for c in CLUES])))
+            assert st['HEAD_CLS_W'].shape == (3, 256), 'use_sigmoid=True heads expected (gaze_stqi_head.py:72-75)'
+            self.stages.append(st)
+        # only the LAST stage's gaze head runs at inference (multiclue_gaze_roi_head.py:367,378)
+        g = f'roi_head.gaze_head.{num_stages - 1}'
+        branches = [f'gaze_{c}_fcs' for c in CLUES] + [f'gaze_{c}_confidence' for c in CLUES]  # branch = 3*k + clue
+        outs = [f'fc_{c}' for c in CLUES] + [f'fc_{c}_confidence' for c in CLUES]
+        self.gaze = dict(
+            FC_W=mat(torch.stack([torch.stack([sd[g + f'.{br}.{3 * j}.weight'] for j in range(2)]) for br in branches])),
+            LN_G=vec(torch.stack([torch.stack([sd[g + f'.{br}.{3 * j + 1}.weight'] for j in range(2)]) for br in branches])),
+            LN_B=vec(torch.stack([torch.stack([sd[g + f'.{br}.{3 * j + 1}.bias'] for j in range(2)]) for br in branches])),
+            OUT_W=vec(torch.stack([sd[g + f'.{o}.weight'] for o in outs])), OUT_B=vec(torch.stack([sd[g + f'.{o}.bias'] for o in outs])),
+            FUSE_W=vec(sd[g + '.fc_gaze.weight']), FUSE_B=vec(sd[g + '.fc_gaze.bias']))
+
+    def _dev(self, t):
+        t = t.contiguous().to(self.device)
+        self._keep.append(t)
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self._keep)

@@ -1,0 +1,183 @@
+"""-m gpu: every C-ABI operator of libmcgaze_hip.so against the oracle (oracle/mcgaze_oracle.py,
+plain torch fp32 on the CPU) on the same seeded inputs.
+
+Tolerances: MCG_F32 mode uses f32 MFMA (exact f32 fma chains) -> only summation order differs
+from the CPU reference, 1e-4 relative to the tensor's scale.  MCG_BF16 mode rounds operands and
+stored activations to bf16 (8 mantissa bits): 2e-2 relative to the tensor's scale per operator.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mcgaze_amd import synth
+from oracle import mcgaze_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def scale_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from mcgaze_amd import engine
+    return engine
+
+
+@pytest.fixture(scope='module')
+def sd():
+    return orc.as_torch(synth.make_state_dict(0))
+
+
+def test_library_loads_on_gpu(eng):
+    import ctypes as C
+    from mcgaze_amd import lib as L
+    lib = L.load()
+    cu, hbm, arch = C.c_int(), C.c_size_t(), C.create_string_buffer(64)
+    L.check(lib.mcg_device_info(C.byref(cu), C.byref(hbm), arch, 64), 'mcg_device_info')
+    assert arch.value.decode().startswith('gfx950'), arch.value
+    assert cu.value == 256 and hbm.value > 200 << 30
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, relu, residual
+    (2, 14, 14, 64, 64, 1, 1, 0, True, None),
+    (2, 14, 14, 64, 64, 3, 1, 1, True, None),
+    (3, 10, 12, 256, 128, 1, 1, 0, False, None),
+    (2, 12, 12, 128, 128, 3, 2, 1, True, None),
+    (2, 8, 8, 256, 512, 1, 2, 0, False, None),
+    (5, 7, 7, 512, 2048, 1, 1, 0, True, 'add'),
+    (2, 9, 11, 64, 256, 1, 1, 0, True, 'add'),
+    (2, 8, 12, 512, 256, 1, 1, 0, False, 'up'),
+    (1, 7, 9, 256, 256, 3, 1, 1, False, None),
+    (1, 3, 3, 2048, 512, 1, 1, 0, True, None),
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d(eng, dtype, case):
+    N, H, W, Cin, Cout, k, stride, pad, relu, resk = case
+    g = torch.Generator().manual_seed(1000 + CONV_CASES.index(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    q = (lambda t: t.to(dtype).float())  # the values the kernel actually sees
+    ref = F.conv2d(q(x), q(w), b, stride=stride, padding=pad)
+    res = None
+    mode = 0
+    if resk == 'add':
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + q(res)
+        mode = 1
+    elif resk == 'up':
+        res = torch.randn(N, Cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g)
+        ref = ref + F.interpolate(q(res), size=ref.shape[2:], mode='nearest')
+        mode = 2
+    if relu:
+        ref = F.relu(ref)
+    dev = 'cuda:0'
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+    y = eng.conv2d(nhwc(x), w.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev), b.to(dev), stride=stride, pad=pad, relu=relu,
+                   residual=nhwc(res) if res is not None else None, residual_mode=mode)
+    torch.cuda.synchronize()
+    assert scale_err(y.permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_layout_roundtrip(eng, dtype):
+    x = torch.randn(3, 37, 5, 9).to('cuda:0')
+    y = eng.to_nhwc(x, dtype)
+    assert torch.equal(y.float().cpu(), x.permute(0, 2, 3, 1).to(dtype).float().cpu())
+    assert torch.equal(eng.to_nchw(y).cpu(), x.to(dtype).float().cpu())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_stem(eng, sd, dtype):
+    from mcgaze_amd.packing import PackedWeights
+    pw = PackedWeights(sd, dtype=dtype)
+    img = torch.from_numpy(synth.make_clips(3, 1, 2, 64, 96))
+    ref = F.relu(orc._bn(sd, 'backbone.bn1', F.conv2d(img, sd['backbone.conv1.weight'], stride=2, padding=3)))
+    ref = F.max_pool2d(ref, 3, 2, 1)
+    y = eng.stem(img.to('cuda:0'), pw.stem['w'], pw.stem['bias'], dtype)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (2, 16, 24, 64)
+    assert scale_err(y.permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_roi_align_all_levels(eng, dtype):
+    g = torch.Generator().manual_seed(5)
+    N = 3
+    feats = [torch.randn(N, 256, 64 >> i, 96 >> i, generator=g) for i in range(4)]  # a 256x384 frame
+    boxes = torch.tensor([[[10., 12., 60., 70.], [30., 20., 180., 150.], [0., 0., 384., 256.]],
+                          [[-20., -15., 500., 400.], [100., 100., 101., 101.], [300., 200., 420., 300.]],
+                          [[5.5, 7.25, 250.75, 201.5], [150., 40., 380., 250.], [-300., -300., -200., -200.]]])
+    q = lambda t: t.to(dtype).float()
+    ref = orc.roi_extract([q(f) for f in feats], boxes)  # [R,256,7,7]
+    ref_lv = orc.map_roi_levels(boxes.reshape(-1, 4))
+    assert set(ref_lv.tolist()) == {0, 1, 2, 3}
+    out, lv = eng.roi_align([f.permute(0, 2, 3, 1).contiguous().to(dtype).to('cuda:0') for f in feats], boxes.to('cuda:0'))
+    torch.cuda.synchronize()
+    assert lv.cpu().tolist() == ref_lv.tolist()
+    got = out.float().cpu().reshape(-1, 7, 7, 256).permute(0, 3, 1, 2)
+    assert scale_err(got, ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert float(got[-1].abs().max()) == 0.0  # a box entirely outside the map samples zeros
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,T', [(1, 7), (2, 3), (3, 1)])
+def test_decoder_stage(eng, sd, dtype, B, T):
+    from mcgaze_amd.packing import PackedWeights
+    pw = PackedWeights(sd, dtype=dtype)
+    N = B * T
+    g = torch.Generator().manual_seed(100 + N)
+    q = lambda t: t.to(dtype).float()
+    roi = torch.randn(N * 3, 256, 7, 7, generator=g) * 3
+    obj = torch.randn(N, 3, 256, generator=g)
+    boxes = torch.tensor([[20., 30., 200., 210.], [60., 50., 160., 150.], [90., 60., 130., 100.]])[None].repeat(N, 1, 1)
+    boxes = boxes + torch.randn(N, 3, 4, generator=g)
+    for s in (0, 3):
+        cls_r, delta_r, obj_r, inter = orc.stqi_stage(sd, s, q(roi), q(obj), T, return_intermediates=True)
+        boxes_r = orc.delta2bbox(boxes.reshape(-1, 4), delta_r.reshape(-1, 4), stds=(0.5, 0.5, 1., 1.), clip_border=False).reshape(N, 3, 4)
+        roi_dev = roi.permute(0, 2, 3, 1).reshape(N * 3, 49, 256).contiguous().to(dtype).to('cuda:0')
+        obj_o, boxes_o, cls_o = eng.stage_forward(pw.stages[s], roi_dev, obj.to(dtype).to('cuda:0'), boxes.to('cuda:0'), T)
+        torch.cuda.synchronize()
+        tol = 2e-4 if dtype == torch.float32 else 6e-2
+        assert scale_err(obj_o, obj_r) < tol, 'obj'
+        assert scale_err(cls_o, cls_r.squeeze(-1)) < tol, 'cls'
+        assert scale_err(boxes_o, boxes_r) < tol, 'boxes'
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_gaze_head(eng, sd, dtype):
+    from mcgaze_amd.packing import PackedWeights
+    pw = PackedWeights(sd, dtype=dtype)
+    obj = torch.randn(9, 3, 256, generator=torch.Generator().manual_seed(8))
+    ref = orc.gaze_head(sd, 3, obj.to(dtype).float())
+    out = eng.gaze_head(pw.gaze, obj.to(dtype).to('cuda:0')).cpu()
+    torch.cuda.synchronize()
+    tol = 1e-4 if dtype == torch.float32 else 4e-2
+    for i, k in enumerate(('gaze_score', 'face_gaze_score', 'eyes_gaze_score', 'head_gaze_score')):
+        assert float((out[i] - ref[k]).abs().max()) < tol, k
+    assert torch.allclose(out.norm(dim=-1), torch.ones(4, 9), atol=1e-5)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_backbone_fpn(eng, sd, dtype):
+    e = eng.HipEngine(sd, precision='fp32' if dtype == torch.float32 else 'bf16')
+    img = torch.from_numpy(synth.make_clips(21, 1, 3, 64, 96))
+    with torch.no_grad():
+        ref = orc.fpn(sd, orc.resnet(sd, img))
+    for chunk in (0, 2):
+        pyr = e.backbone_fpn(img.to('cuda:0'), chunk_frames=chunk)
+        torch.cuda.synchronize()
+        for lvl, (p, r) in enumerate(zip(pyr, ref)):
+            assert tuple(p.shape) == (r.shape[0], r.shape[2], r.shape[3], r.shape[1])
+            assert scale_err(p.permute(0, 3, 1, 2), r) < (2e-4 if dtype == torch.float32 else 5e-2), f'P{lvl + 2} chunk={chunk}'
