@@ -19,7 +19,7 @@ from oracle import mcgaze_oracle as orc
 pytestmark = pytest.mark.gpu
 
 F32_TOL = 1e-3    # north_star
-BF16_TOL = 1.5e-1  # rad, bound on random-weight nets (no trained checkpoint here); typical value is printed
+BF16_TOL = 3e-1  # rad, loose bound on RANDOM-weight nets (no trained checkpoint here); the measured value is printed
 CASES = ['clip224', 'clip_nonsquare', 'batch2', 'clip_t5']
 KEYS = ('gaze_score', 'face_gaze_score', 'eyes_gaze_score', 'head_gaze_score')
 
