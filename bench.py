@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py -- clips/s of the MCGaze per-clip forward path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the whole hot path (R-50 + FPN per frame, 4 decoder stages, gaze head)
+over one batch of synthetic clips already resident in HBM:  --clips-per-gpu clips (default 64 =
+BASELINE.json configs[2]) x 7 frames x 3 x 224 x 224 per GPU, bf16 MFMA engine.  With N > 1 every
+rank processes its own 64 clips (weak scaling, configs[3]: 8 x 64 = 512 clips) and the per-rank
+results are exchanged with ONE fused RCCL all_gather per step.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_PER_CLIP = 99.55e9          # 2*MAC over convs + linears + bmms, 7x3x224x224 clip
+PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+CFG_NAMES = {0: 'f32 128x64 k64B', 1: 'f32 128x64 k128B', 2: 'f32 128x128 k64B', 3: 'f32 128x128 k128B',
+             4: 'bf16 128x64 k64B', 5: 'bf16 128x64 k128B', 6: 'bf16 128x128 k64B', 7: 'bf16 128x128 k128B'}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--clips-per-gpu', type=int, default=64)
+    ap.add_argument('--clip-length', type=int, default=7)
+    ap.add_argument('--size', type=int, default=224)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--chunk-frames', type=int, default=0)
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline leg (rank 0, N=1 only); 0 disables')
+    ap.add_argument('--kernel-events', default='first', choices=['first', 'none'],
+                    help="'first': bracket every contraction-kernel launch of the FIRST timed step with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds, clip_length, size):
+    """The CPU oracle (fp32 torch restatement proven equal to the reference, tests/test_oracle.py)
+    timed on the host cores, one clip per forward like the reference harness
+    (tools/test_gaze360_gaze.py:77-111), on a bounded sample of the same synthetic workload."""
+    from mcgaze_amd import synth
+    from oracle import mcgaze_oracle as orc
+    sd = orc.as_torch(synth.make_state_dict(0))
+    metas = synth.make_img_metas(clip_length, (size, size, 3))
+    clips = synth.make_clips(3, 2, clip_length, size, size)
+    orc.forward(sd, clips[:clip_length], metas, clip_length)  # warm-up
+    n, t0 = 0, time.time()
+    while time.time() - t0 < seconds:
+        orc.forward(sd, clips[(n % 2) * clip_length:(n % 2 + 1) * clip_length], metas, clip_length)
+        n += 1
+    dt = time.time() - t0
+    return {'value': round(n / dt, 3), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} clips of {clip_length}x3x{size}x{size}, one clip per forward, fp32 oracle (oracle/mcgaze_oracle.py), '
+                      f'{dt:.1f} s on {os.cpu_count()} logical CPUs'}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run for N > 1'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from mcgaze_amd import lib as L
+    from mcgaze_amd import synth
+    from mcgaze_amd.engine import HipEngine
+    from mcgaze_amd.dist import ResultGather
+
+    lib = L.load()
+    B, T = a.clips_per_gpu, a.clip_length
+    N = B * T
+    eng = HipEngine(synth.make_state_dict(0), precision=a.precision, device=dev)
+    img = torch.from_numpy(synth.make_clips(3 + rank, B, T, a.size, a.size)).to(dev)
+    gather = ResultGather(N, world, dev)
+    out = gather.local_views()  # the engine writes its results straight into the fused exchange buffer
+    eng.forward(img, T, chunk_frames=a.chunk_frames, out=out)
+
+    def step():
+        eng.forward(img, T, chunk_frames=a.chunk_frames, out=out)
+        if world > 1:
+            gather.all_gather()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(a.warmup, 1)):
+        step()
+    torch.cuda.synchronize(dev)
+    launches = 0
+    if a.kernel_events == 'first':  # count contraction-kernel launches per step (untimed), then arm for the first timed step
+        cnt = C.c_int()
+        L.check(lib.mcg_profile_start(4096), 'mcg_profile_start')
+        eng.forward(img, T, chunk_frames=a.chunk_frames, out=out)
+        L.check(lib.mcg_profile_stop(C.byref(cnt), None, None, None, 4096), 'mcg_profile_stop')
+        launches = cnt.value
+        L.check(lib.mcg_profile_start(launches), 'mcg_profile_start')
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    roofline = None
+    if a.kernel_events == 'first':
+        cnt = C.c_int()
+        ms = (C.c_float * launches)(); fl = (C.c_double * launches)(); cf = (C.c_int * launches)()
+        L.check(lib.mcg_profile_stop(C.byref(cnt), ms, fl, cf, launches), 'mcg_profile_stop')
+        rec = [(ms[i], fl[i], cf[i]) for i in range(cnt.value)]
+        by = {}
+        for t, f, c in rec:
+            d = by.setdefault(c, [0.0, 0.0, 0])
+            d[0] += t; d[1] += f; d[2] += 1
+        dom = max(by, key=lambda c: by[c][0])
+        t_ms, flops, n = by[dom]
+        achieved = flops / (t_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if dom >= 4 else PEAK_F32_TFLOPS
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(CFG_NAMES[dom])
+        roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                    'traffic': traffic, 'kernel': f'igemm_kernel<{CFG_NAMES[dom]}>', 'launches_per_step': n,
+                    'avg_launch_ms': round(t_ms / n, 4), 'algorithmic_gflop_per_launch': round(flops / n / 1e9, 2),
+                    'all_contraction_launches': {CFG_NAMES[c]: {'launches': v[2], 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
+                                                 for c, v in sorted(by.items())},
+                    'sampled': 'every contraction launch of the first timed step, HIP events on the launch stream'}
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        total_clips = B * world * a.steps
+        value = total_clips / elapsed
+        line = {
+            'metric': 'clips/sec (7x3x224x224)', 'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic (seeded N(0,1) clips, random-init weights, resident in HBM)',
+            'config': {'workload': f'full multiclue_gaze_r50 forward (R-50 + FPN + 4 decoder stages + gaze head), '
+                                   f'{B} clips/GPU x {T} frames x 3x{a.size}x{a.size}, {B * world} clips/step',
+                       'clips_per_gpu': B, 'clip_length': T, 'global_clips': B * world, 'chunk_frames': a.chunk_frames,
+                       'parallelism': f'dp{world} (clips sharded by rank, one fused all_gather of results per step)' if world > 1 else 'single GPU'},
+            'model_tflops': round(value * FLOPS_PER_CLIP / 1e12, 1),
+            'frac_of_bf16_mfma_peak': round(value * FLOPS_PER_CLIP / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+            'roofline': roofline,
+        }
+        if world == 1 and a.cpu_seconds > 0:
+            line['cpu_baseline'] = cpu_baseline(a.cpu_seconds, T, a.size)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -30,6 +30,44 @@ extern "C" int mcg_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int
   return MCG_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Per-launch profiling of the contraction kernel (bench.py's roofline line): when armed, every
+// igemm launch is bracketed by a hipEvent pair on the launch stream and tagged with its
+// algorithmic FLOPs (2*M*Cout*K, true K for the zero-padded stem) and tile configuration.
+struct ProfRec { hipEvent_t a, b; double flops; int cfg; };
+static ProfRec* g_prof = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0;
+extern "C" int mcg_profile_start(int capacity) {
+  if (g_prof) { mcg_set_error("mcg_profile_start: already armed"); return MCG_ERR_ARG; }
+  MCG_CHECK_ARG(capacity > 0 && capacity <= (1 << 20), "mcg_profile_start: bad capacity %d", capacity);
+  g_prof = new ProfRec[capacity];
+  for (int i = 0; i < capacity; ++i) {
+    if (hipEventCreate(&g_prof[i].a) != hipSuccess || hipEventCreate(&g_prof[i].b) != hipSuccess) {
+      mcg_set_error("mcg_profile_start: hipEventCreate failed");
+      return MCG_ERR_HIP;
+    }
+  }
+  g_prof_cap = capacity; g_prof_n = 0;
+  return MCG_OK;
+}
+extern "C" int mcg_profile_stop(int* count, float* ms, double* flops, int* cfg, int capacity) {
+  if (!g_prof) { mcg_set_error("mcg_profile_stop: not armed"); return MCG_ERR_ARG; }
+  const int n = g_prof_n;
+  int rc = MCG_OK;
+  for (int i = 0; i < n; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(g_prof[i].b) != hipSuccess || hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) rc = MCG_ERR_HIP;
+    if (i < capacity) { if (ms) ms[i] = t; if (flops) flops[i] = g_prof[i].flops; if (cfg) cfg[i] = g_prof[i].cfg; }
+  }
+  for (int i = 0; i < g_prof_cap; ++i) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
+  delete[] g_prof;
+  g_prof = nullptr; g_prof_cap = 0; g_prof_n = 0;
+  if (count) *count = n < capacity ? n : capacity;
+  if (rc != MCG_OK) mcg_set_error("mcg_profile_stop: event query failed");
+  return rc;
+}
+
 template <typename T, int BM, int BN, int BKB, int WM, int WN>
 static void launch_cfg(hipStream_t s, const IgemmParams& p, int groups) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
@@ -44,6 +82,13 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   const bool wide = (p.Cin * ES) % 128 == 0;
   MCG_CHECK_ARG((p.Cin * ES) % 64 == 0, "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
   MCG_CHECK_ARG(p.Cout % (16 / ES) == 0, "igemm: Cout=%d must be a multiple of %d", p.Cout, 16 / ES);
+  const int cfg = (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
+  ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
+  if (rec) {
+    rec->cfg = cfg;
+    rec->flops = 2.0 * p.M * p.Cout * (p.algo_k > 0 ? (double)p.algo_k : (double)p.KH * p.KW * p.Cin) * groups;
+    (void)hipEventRecord(rec->a, s);
+  }
   if (p.Cout <= 64) {
     if (wide) launch_cfg<T, 128, 64, 128, 4, 1>(s, p, groups);
     else launch_cfg<T, 128, 64, 64, 4, 1>(s, p, groups);
@@ -51,6 +96,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     if (wide) launch_cfg<T, 128, 128, 128, 2, 2>(s, p, groups);
     else launch_cfg<T, 128, 128, 64, 2, 2>(s, p, groups);
   }
+  if (rec) (void)hipEventRecord(rec->b, s);
   MCG_CHECK_LAUNCH("igemm launch");
   return MCG_OK;
 }
@@ -210,6 +256,7 @@ extern "C" int mcg_stem_forward(mcg_stream s_, mcg_dtype dt, const float* img, c
   p.Ho = Hc; p.Wo = Wc; p.M = N * Hc * Wc; p.H = Hp; p.W = Wp; p.Cin = 32; p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 0; p.Cout = 64;
   p.xs_w = 4; p.xs_h = (long long)Wp * 4; p.xs_n = (long long)Hp * Wp * 4; p.nocheck = 1;
   p.y_row_stride = 64; p.relu = 1; p.res_mode = MCG_RES_NONE; p.splitk = 1; p.tiles_per_slice = 1 << 30;
+  p.algo_k = 147;  // 7*7*3 real taps; the packed K of 224 carries zero weights
   MCG_TRY(launch_igemm(s, dt, p, 1));
   const int Ho = (Hc + 2 - 3) / 2 + 1, Wo = (Wc + 2 - 3) / 2 + 1;
   const long long nchunks = (long long)N * Ho * Wo * (64 / (16 / (int)es));

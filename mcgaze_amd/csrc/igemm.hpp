@@ -31,6 +31,7 @@ struct IgemmParams {
   long long x_g, w_g, y_g, res_g;  // per-group element offsets (blockIdx.z)
   int bias_g;
   int splitk, tiles_per_slice;
+  int algo_k;  // algorithmic K for FLOP accounting when the packed K carries zero padding (stem); 0 = KH*KW*Cin
 };
 
 template <typename T, int BM, int BN, int BKB, int WAVES_M, int WAVES_N>

@@ -1,0 +1,50 @@
+"""Multi-GPU: clips are independent (no cross-clip state: spatial attention is within a frame,
+temporal attention within a clip, BN is in eval mode -- SURVEY.md section 8(e)), so the path
+shards by clip with NO data-path collective.  The only exchange is one all_gather of the small
+per-rank result block per step: gaze [4,N,3] + boxes [N,3,4] + scores [N,3] = 27 floats/frame
+(756 B/clip at T=7), fused into ONE buffer and ONE collective (RCCL over xGMI on the GPU box,
+gloo in the CPU tests).  The engine writes its outputs directly into the fused buffer's views.
+"""
+import torch
+
+FLOATS_PER_FRAME = 4 * 3 + 3 * 4 + 3
+
+
+def shard_clips(num_clips, world, rank):
+    """Contiguous block of clips for ``rank`` (sizes differ by at most one)."""
+    base, rem = divmod(num_clips, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def _views(buf, n):
+    return dict(gaze=buf[:12 * n].view(4, n, 3), boxes=buf[12 * n:24 * n].view(n, 3, 4), scores=buf[24 * n:27 * n].view(n, 3))
+
+
+class ResultGather:
+    """Fused result buffer for ``frames_per_rank`` frames per rank + its all_gather."""
+
+    def __init__(self, frames_per_rank, world, device):
+        self.n, self.world = frames_per_rank, world
+        self.local = torch.zeros(FLOATS_PER_FRAME * frames_per_rank, dtype=torch.float32, device=device)
+        self.all = torch.zeros(world * FLOATS_PER_FRAME * frames_per_rank, dtype=torch.float32, device=device) if world > 1 else self.local
+
+    def local_views(self):
+        return _views(self.local, self.n)
+
+    def all_gather(self, group=None):
+        if self.world == 1:
+            return self.all
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self.all, self.local, group=group)
+        return self.all
+
+    def rank_views(self, rank):
+        per = FLOATS_PER_FRAME * self.n
+        return _views(self.all[rank * per:(rank + 1) * per], self.n)
+
+    def merged(self):
+        """Results of all ranks concatenated in rank (= clip) order."""
+        parts = [self.rank_views(r) for r in range(self.world)]
+        return dict(gaze=torch.cat([p['gaze'] for p in parts], dim=1), boxes=torch.cat([p['boxes'] for p in parts]),
+                    scores=torch.cat([p['scores'] for p in parts]))

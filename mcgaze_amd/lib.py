@@ -26,7 +26,7 @@ SW_COUNT, GW_COUNT = len(STAGE_KEYS), len(GAZE_KEYS)
 EXPORTS = ['mcg_abi_version', 'mcg_last_error', 'mcg_device_info', 'mcg_nchw_to_nhwc', 'mcg_nhwc_to_nchw', 'mcg_conv2d',
            'mcg_stem_workspace_bytes', 'mcg_stem_forward', 'mcg_roi_align', 'mcg_stage_workspace_bytes', 'mcg_stage_forward',
            'mcg_gaze_head_workspace_bytes', 'mcg_gaze_head', 'mcg_engine_create', 'mcg_engine_destroy',
-           'mcg_engine_workspace_bytes', 'mcg_backbone_fpn_forward', 'mcg_clip_forward']
+           'mcg_engine_workspace_bytes', 'mcg_backbone_fpn_forward', 'mcg_clip_forward', 'mcg_profile_start', 'mcg_profile_stop']
 
 
 class ConvDesc(C.Structure):
@@ -88,6 +88,8 @@ def load():
     lib.mcg_engine_workspace_bytes.argtypes = [vp, i, i, i, i]
     lib.mcg_backbone_fpn_forward.argtypes = [vp, vp, vp, i, i, i, i, C.POINTER(vp), vp, sz]
     lib.mcg_clip_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp, vp, vp, vp, sz]
+    lib.mcg_profile_start.argtypes = [i]
+    lib.mcg_profile_stop.argtypes = [C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i), i]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('mcg_abi_version',):
