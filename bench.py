@@ -114,7 +114,7 @@ def main():
         cnt = C.c_int()
         L.check(lib.mcg_profile_start(4096), 'mcg_profile_start')
         eng.forward(img, T, chunk_frames=a.chunk_frames, out=out)
-        L.check(lib.mcg_profile_stop(C.byref(cnt), None, None, None, 4096), 'mcg_profile_stop')
+        L.check(lib.mcg_profile_stop(C.byref(cnt), None, None, None, None, 4096), 'mcg_profile_stop')
         launches = cnt.value
         L.check(lib.mcg_profile_start(launches), 'mcg_profile_start')
 
@@ -129,7 +129,7 @@ def main():
     if a.kernel_events == 'first':
         cnt = C.c_int()
         ms = (C.c_float * launches)(); fl = (C.c_double * launches)(); cf = (C.c_int * launches)()
-        L.check(lib.mcg_profile_stop(C.byref(cnt), ms, fl, cf, launches), 'mcg_profile_stop')
+        L.check(lib.mcg_profile_stop(C.byref(cnt), ms, fl, cf, None, launches), 'mcg_profile_stop')
         rec = [(ms[i], fl[i], cf[i]) for i in range(cnt.value)]
         by = {}
         for t, f, c in rec:

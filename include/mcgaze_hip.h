@@ -180,9 +180,10 @@ int mcg_clip_forward(mcg_engine* e, mcg_stream s, const float* img, int num_fram
 /* ---------------------------------------------------------------- measurement aid (bench.py)
  * While armed, every launch of the implicit-GEMM kernel is bracketed by a hipEvent pair on its
  * launch stream.  mcg_profile_stop synchronises, returns per-launch duration (ms), algorithmic
- * FLOPs and tile-configuration id (bit2: bf16, bit1: BN=128, bit0: 128-byte K slices), and disarms. */
+ * FLOPs, tile-configuration id (bit2: bf16, bit1: BN=128, bit0: 128-byte K slices) and the GEMM
+ * shape (M, N, K) of every recorded launch (any output array may be NULL), and disarms. */
 int mcg_profile_start(int capacity);
-int mcg_profile_stop(int* count, float* ms, double* flops, int* cfg, int capacity);
+int mcg_profile_stop(int* count, float* ms, double* flops, int* cfg, int* shape_mnk, int capacity);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,7 @@ extern "C" int mcg_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int
 // Per-launch profiling of the contraction kernel (bench.py's roofline line): when armed, every
 // igemm launch is bracketed by a hipEvent pair on the launch stream and tagged with its
 // algorithmic FLOPs (2*M*Cout*K, true K for the zero-padded stem) and tile configuration.
-struct ProfRec { hipEvent_t a, b; double flops; int cfg; };
+struct ProfRec { hipEvent_t a, b; double flops; int cfg; int shape[3]; };
 static ProfRec* g_prof = nullptr;
 static int g_prof_cap = 0, g_prof_n = 0;
 extern "C" int mcg_profile_start(int capacity) {
@@ -51,14 +51,19 @@ extern "C" int mcg_profile_start(int capacity) {
   g_prof_cap = capacity; g_prof_n = 0;
   return MCG_OK;
 }
-extern "C" int mcg_profile_stop(int* count, float* ms, double* flops, int* cfg, int capacity) {
+extern "C" int mcg_profile_stop(int* count, float* ms, double* flops, int* cfg, int* shape, int capacity) {
   if (!g_prof) { mcg_set_error("mcg_profile_stop: not armed"); return MCG_ERR_ARG; }
   const int n = g_prof_n;
   int rc = MCG_OK;
   for (int i = 0; i < n; ++i) {
     float t = 0.f;
     if (hipEventSynchronize(g_prof[i].b) != hipSuccess || hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) rc = MCG_ERR_HIP;
-    if (i < capacity) { if (ms) ms[i] = t; if (flops) flops[i] = g_prof[i].flops; if (cfg) cfg[i] = g_prof[i].cfg; }
+    if (i < capacity) {
+      if (ms) ms[i] = t;
+      if (flops) flops[i] = g_prof[i].flops;
+      if (cfg) cfg[i] = g_prof[i].cfg;
+      if (shape) { shape[3 * i] = g_prof[i].shape[0]; shape[3 * i + 1] = g_prof[i].shape[1]; shape[3 * i + 2] = g_prof[i].shape[2]; }
+    }
   }
   for (int i = 0; i < g_prof_cap; ++i) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
   delete[] g_prof;
@@ -86,6 +91,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
   if (rec) {
     rec->cfg = cfg;
+    rec->shape[0] = p.M; rec->shape[1] = p.Cout * groups; rec->shape[2] = p.KH * p.KW * p.Cin;
     rec->flops = 2.0 * p.M * p.Cout * (p.algo_k > 0 ? (double)p.algo_k : (double)p.KH * p.KW * p.Cin) * groups;
     (void)hipEventRecord(rec->a, s);
   }

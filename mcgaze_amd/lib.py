@@ -89,7 +89,7 @@ def load():
     lib.mcg_backbone_fpn_forward.argtypes = [vp, vp, vp, i, i, i, i, C.POINTER(vp), vp, sz]
     lib.mcg_clip_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp, vp, vp, vp, sz]
     lib.mcg_profile_start.argtypes = [i]
-    lib.mcg_profile_stop.argtypes = [C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i), i]
+    lib.mcg_profile_stop.argtypes = [C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i), C.POINTER(i), i]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('mcg_abi_version',):

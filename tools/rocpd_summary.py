@@ -1,0 +1,13 @@
+"""Summarise a rocprofv3 rocpd sqlite database (kernel trace) as a per-kernel table.
+Usage: python tools/rocpd_summary.py <results.db> [out.md]"""
+import sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+rows = db.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc').fetchall()
+total = sum(r[2] for r in rows)
+out = ['| kernel | calls | total ms | avg us | min us | max us | % |', '|---|---|---|---|---|---|---|']
+for n, c, s, a, lo, hi in rows:
+    out.append(f'| `{n[:110]}` | {c} | {s / 1e6:.3f} | {a / 1e3:.1f} | {lo / 1e3:.1f} | {hi / 1e3:.1f} | {100 * s / total:.2f} |')
+text = '\n'.join(out)
+if len(sys.argv) > 2:
+    open(sys.argv[2], 'w').write(text + '\n')
+print(text)
