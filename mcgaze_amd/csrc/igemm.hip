@@ -1,8 +1,9 @@
 // Host launchers for the implicit-GEMM kernel + the trunk's memory-bound helpers
 // (stem input packing, 3x3/s2 max-pool, NCHW<->NHWC).
-#include "igemm.hpp"
+#include "igemm_dma.hpp"
 
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -80,14 +81,40 @@ static void launch_cfg(hipStream_t s, const IgemmParams& p, int groups) {
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, BKB, WM, WN>), grid, dim3(256), 0, s, p);
 }
 
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int ST>
+static void launch_dma(hipStream_t s, const IgemmParams& p, int groups) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+  dim3 grid(tiles, p.splitk, groups);
+  hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, BKB, WM, WN, ST>), grid, dim3(64 * WM * WN), 0, s, p);
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 template <typename T>
 static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   constexpr int ES = (int)sizeof(T);
-  // K-slice width: 128 bytes of K per row when the tap vector allows it, else 64.
-  const bool wide = (p.Cin * ES) % 128 == 0;
+  // tuning knobs (experiments): MCG_IGEMM=1 selects the register-staged kernel for bf16 too,
+  // MCG_FORCE_NARROW=1 its 64-byte K slices, MCG_TILE=1 the 256x128 DMA tile.
+  static const int use_v1 = env_int("MCG_IGEMM", 0), force_narrow = env_int("MCG_FORCE_NARROW", 0), big_tile = env_int("MCG_TILE", -1);
+  const bool dma = ES == 2 && !use_v1;
+  const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0;
   MCG_CHECK_ARG((p.Cin * ES) % 64 == 0, "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
   MCG_CHECK_ARG(p.Cout % (16 / ES) == 0, "igemm: Cout=%d must be a multiple of %d", p.Cout, 16 / ES);
-  const int cfg = (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
+  // DMA tile choice (profiles/r01_b_tile_sweep.md): 0 = 128x128 4 waves 4 stages, 1 = 256x128 4 waves,
+  // 3 = 256x256 8 waves, 5 = 256x128 8 waves with 128-byte K slices.  MCG_TILE >= 0 overrides (experiments).
+  int tile = 0;
+  if (dma && p.Cout > 64 && p.M >= 128 * 256) {
+    const int Kdim = p.KH * p.KW * p.Cin;
+    if (big_tile >= 0) tile = big_tile;
+    else if (p.Cout <= 128) tile = Kdim >= 1024 ? 1 : 0;
+    else if (p.M >= 300000) tile = 3;
+    else if (p.M >= 80000) tile = p.Cout >= 512 ? 3 : ((p.Cin * ES) % 128 == 0 ? 5 : 1);
+    else tile = 1;
+  }
+  const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
   ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
   if (rec) {
     rec->cfg = cfg;
@@ -95,7 +122,15 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     rec->flops = 2.0 * p.M * p.Cout * (p.algo_k > 0 ? (double)p.algo_k : (double)p.KH * p.KW * p.Cin) * groups;
     (void)hipEventRecord(rec->a, s);
   }
-  if (p.Cout <= 64) {
+  if (dma) {
+    if (p.Cout <= 64) launch_dma<T, 128, 64, 64, 4, 1, 4>(s, p, groups);
+    else if (tile == 1) launch_dma<T, 256, 128, 64, 2, 2, 3>(s, p, groups);
+    else if (tile == 2) launch_dma<T, 256, 128, 64, 4, 2, 3>(s, p, groups);
+    else if (tile == 3) launch_dma<T, 256, 256, 64, 4, 2, 3>(s, p, groups);
+    else if (tile == 4 && (p.Cin * ES) % 128 == 0) launch_dma<T, 128, 128, 128, 2, 2, 3>(s, p, groups);
+    else if (tile == 5 && (p.Cin * ES) % 128 == 0) launch_dma<T, 256, 128, 128, 4, 2, 3>(s, p, groups);
+    else launch_dma<T, 128, 128, 64, 2, 2, 4>(s, p, groups);
+  } else if (p.Cout <= 64) {
     if (wide) launch_cfg<T, 128, 64, 128, 4, 1>(s, p, groups);
     else launch_cfg<T, 128, 64, 64, 4, 1>(s, p, groups);
   } else {
@@ -135,7 +170,8 @@ int launch_linear_splitk(hipStream_t s, mcg_dtype dt, const void* x, long long l
                          int M, int K, int Cout, int want_slices, int* splitk_out) {
   IgemmParams p = linear_params(x, lda, w, M, K, Cout);
   const int es = dt == MCG_BF16 ? 2 : 4;
-  const int bk = (((long long)K * es) % 128 == 0 ? 128 : 64) / es;
+  const bool dma = dt == MCG_BF16 && !env_int("MCG_IGEMM", 0);
+  const int bk = (dma || env_int("MCG_FORCE_NARROW", 0) ? 64 : (((long long)K * es) % 128 == 0 ? 128 : 64)) / es;
   const int KT = K / bk;
   int slices = want_slices < 1 ? 1 : (want_slices > KT ? KT : want_slices);
   const int per = (KT + slices - 1) / slices;
