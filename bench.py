@@ -28,9 +28,14 @@ sys.path.insert(0, ROOT)
 FLOPS_PER_CLIP = 99.55e9          # 2*MAC over convs + linears + bmms, 7x3x224x224 clip
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
-CFG_NAMES = {0: 'f32 128x64 k64B', 1: 'f32 128x64 k128B', 2: 'f32 128x128 k64B', 3: 'f32 128x128 k128B',
-             4: 'bf16 128x64 k64B', 5: 'bf16 128x64 k128B', 6: 'bf16 128x128 k64B', 7: 'bf16 128x128 k128B'}
-
+CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,64,128,4,1>', 2: 'igemm_kernel<float,128,128,64,2,2>',
+             3: 'igemm_kernel<float,128,128,128,2,2>', 4: 'igemm_kernel<bf16,128,64,64,4,1>', 5: 'igemm_kernel<bf16,128,64,128,4,1>',
+             6: 'igemm_kernel<bf16,128,128,64,2,2>', 7: 'igemm_kernel<bf16,128,128,128,2,2>',
+             # LDS-DMA pipelined kernel: <dtype, BM, BN, K-slice bytes, waves M, waves N, stages>
+             15: 'igemm_dma_kernel<bf16,128,64,64,4,1,4>', 16: 'igemm_dma_kernel<bf16,128,128,64,2,2,4>',
+             17: 'igemm_dma_kernel<bf16,256,128,64,2,2,3>', 18: 'igemm_dma_kernel<bf16,256,128,64,4,2,3>',
+             19: 'igemm_dma_kernel<bf16,256,256,64,4,2,3>', 20: 'igemm_dma_kernel<bf16,128,128,128,2,2,3>',
+             21: 'igemm_dma_kernel<bf16,256,128,128,4,2,3>'}
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -144,7 +149,7 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(CFG_NAMES[dom])
         roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                    'traffic': traffic, 'kernel': f'igemm_kernel<{CFG_NAMES[dom]}>', 'launches_per_step': n,
+                    'traffic': traffic, 'kernel': CFG_NAMES[dom], 'launches_per_step': n,
                     'avg_launch_ms': round(t_ms / n, 4), 'algorithmic_gflop_per_launch': round(flops / n / 1e9, 2),
                     'all_contraction_launches': {CFG_NAMES[c]: {'launches': v[2], 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
                                                  for c, v in sorted(by.items())},
