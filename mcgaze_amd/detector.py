@@ -1,0 +1,408 @@
+"""Host-side mirror of the reference's detector / head registry surface for the gaze path
+(SURVEY.md section 8(b)).  Every class below registers under the reference's name, accepts the
+reference's constructor kwargs and owns parameters with the reference's ``state_dict`` keys, so
+``configs/multiclue_gaze/*.py`` builds unchanged and the authors' ``.pth`` loads with
+``strict=True``.  The classes are parameter holders and validators only: ALL inference arithmetic
+runs in ``libmcgaze_hip.so`` through :class:`mcgaze_amd.engine.HipEngine`; there is no torch
+forward path and no CPU fallback (calling a sub-module's ``forward`` raises).
+
+Reference interfaces mirrored (file:line relative to the upstream repo root):
+  MultiClueGaze            mmdet/models/detectors/multiclue_gaze.py:8-131 (+ base.py:112-174)
+  ResNet / Bottleneck      mmdet/models/backbones/resnet.py:97-658
+  FPN                      mmdet/models/necks/fpn.py:62-204
+  FixedEmbeddingRPNHead    mmdet/models/dense_heads/fixed_embedding_rpn_head.py:10-116
+  MultiClueGazeROIHead     mmdet/models/roi_heads/multiclue_gaze_roi_head.py:9-384
+  SingleRoIExtractor       mmdet/models/roi_heads/roi_extractors/single_level_roi_extractor.py:10-115
+  GazeSTQIHead             mmdet/models/roi_heads/bbox_heads/gaze_stqi_head.py:17-202
+  DynamicConv              mmdet/models/utils/transformer.py:1054-1164
+  GazeHead                 mmdet/models/roi_heads/mask_heads/gaze_head.py:14-202
+  DeltaXYWHBBoxCoder       mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:11-114
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .registry import (BBOX_ASSIGNERS, BBOX_CODERS, BBOX_SAMPLERS, MODELS, TRANSFORMER, build_backbone, build_bbox_coder,
+                       build_head, build_loss, build_neck, build_roi_extractor, build_transformer)
+from .synth import ARCH
+
+CLUES = ('face', 'eyes', 'head')
+
+
+class _Holder(nn.Module):
+    """Parameter holder: the arithmetic lives in the HIP library, not here."""
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError(f'{type(self).__name__} has no torch forward path: run the detector (model(img=[...], img_metas=[...], '
+                           f'return_loss=False)), which dispatches to libmcgaze_hip.so')
+
+    def init_weights(self):
+        pass
+
+
+def _check(cond, msg):
+    if not cond:
+        raise NotImplementedError(f'mcgaze_amd: {msg}')
+
+
+# ------------------------------------------------------------------------------------------------ losses etc.
+class _TrainOnly:
+    """Training-only config entries must *parse* (heads construct their losses even at inference,
+    gaze_stqi_head.py:48, bbox_head.py:58-59, gaze_head.py:68-69); using them raises."""
+
+    def __init__(self, **kwargs):
+        self.cfg = dict(kwargs)
+        self.use_sigmoid = bool(kwargs.get('use_sigmoid', False))
+        self.loss_weight = kwargs.get('loss_weight', 1.0)
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError(f'{type(self).__name__}: training is outside the scope of mcgaze_amd (inference hot path only)')
+
+
+for _name in ('L1Loss', 'GIoULoss', 'FocalLoss', 'CrossEntropyLoss', 'GazeArccosLoss', 'GazeTempLoss', 'GazeCosLoss', 'PinballLoss'):
+    MODELS.register_module(name=_name, module=type(_name, (_TrainOnly,), {}))
+BBOX_ASSIGNERS.register_module(name='FixedAssigner', module=type('FixedAssigner', (_TrainOnly,), {}))
+BBOX_SAMPLERS.register_module(name='PseudoSampler', module=type('PseudoSampler', (_TrainOnly,), {}))
+
+
+@BBOX_CODERS.register_module()
+class DeltaXYWHBBoxCoder:
+    def __init__(self, target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.), clip_border=True, add_ctr_clamp=False, ctr_clamp=32):
+        self.means, self.stds = tuple(target_means), tuple(target_stds)
+        self.clip_border, self.add_ctr_clamp, self.ctr_clamp = clip_border, add_ctr_clamp, ctr_clamp
+
+
+# ------------------------------------------------------------------------------------------------ backbone / neck
+class _Bottleneck(_Holder):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)  # style='pytorch': stride on the 3x3
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+
+
+@MODELS.register_module()
+class ResNet(_Holder):
+    def __init__(self, depth, in_channels=3, stem_channels=None, base_channels=64, num_stages=4, strides=(1, 2, 2, 2),
+                 dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style='pytorch', deep_stem=False, avg_down=False,
+                 frozen_stages=-1, conv_cfg=None, norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), plugins=None, with_cp=False, zero_init_residual=True,
+                 pretrained=None, init_cfg=None):
+        super().__init__()
+        if depth not in ARCH:
+            raise KeyError(f'invalid depth {depth} for ResNet (bottleneck depths supported: {sorted(ARCH)})')
+        _check(in_channels == 3 and base_channels == 64 and stem_channels in (None, 64), 'ResNet: only the standard 3->64 stem')
+        _check(num_stages == 4 and tuple(strides) == (1, 2, 2, 2) and tuple(dilations) == (1, 1, 1, 1), 'ResNet: 4 stages, strides (1,2,2,2), no dilation')
+        _check(tuple(out_indices) == (0, 1, 2, 3), 'ResNet: out_indices must be (0,1,2,3) (C2..C5 feed the FPN)')
+        _check(style == 'pytorch' and not deep_stem and not avg_down, "ResNet: style='pytorch', plain stem, conv downsample")
+        _check(conv_cfg is None and dcn is None and plugins is None, 'ResNet: no DCN / plugins / custom conv')
+        _check(norm_cfg.get('type') == 'BN' and norm_eval, 'ResNet: eval-mode BatchNorm (norm_eval=True) is folded into the convs')
+        self.depth, self.stage_blocks = depth, ARCH[depth]
+        self.frozen_stages, self.init_cfg = frozen_stages, init_cfg
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for i, nb in enumerate(self.stage_blocks):
+            planes = 64 * 2 ** i
+            blocks = []
+            for b in range(nb):
+                blocks.append(_Bottleneck(inplanes, planes, stride=(strides[i] if b == 0 else 1), downsample=(b == 0)))
+                inplanes = planes * 4
+            setattr(self, f'layer{i + 1}', nn.Sequential(*blocks))
+
+
+class _ConvModule(nn.Module):
+    def __init__(self, cin, cout, k, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding, bias=True)
+
+
+@MODELS.register_module()
+class FPN(_Holder):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None, norm_cfg=None, act_cfg=None,
+                 upsample_cfg=dict(mode='nearest'), init_cfg=None):
+        super().__init__()
+        assert isinstance(in_channels, (list, tuple))
+        _check(list(in_channels) == [256, 512, 1024, 2048] and out_channels == 256, 'FPN: in_channels [256,512,1024,2048] -> 256')
+        _check(start_level == 0 and end_level in (-1, 4) and num_outs == 4, 'FPN: 4 levels in, 4 levels out (no extra convs are created)')
+        _check(conv_cfg is None and norm_cfg is None and act_cfg is None, 'FPN: conv + bias only (no norm / activation)')
+        _check(dict(upsample_cfg) == dict(mode='nearest'), "FPN: nearest top-down upsampling")
+        self.in_channels, self.out_channels, self.num_outs = list(in_channels), out_channels, num_outs
+        self.lateral_convs = nn.ModuleList(_ConvModule(c, out_channels, 1) for c in in_channels)
+        self.fpn_convs = nn.ModuleList(_ConvModule(out_channels, out_channels, 3, padding=1) for _ in in_channels)
+
+
+# ------------------------------------------------------------------------------------------------ queries
+@MODELS.register_module()
+class FixedEmbeddingRPNHead(_Holder):
+    def __init__(self, proposal_feature_channel=256, num_proposals=3, init_cfg=None, **kwargs):
+        assert init_cfg is None, 'To prevent abnormal initialization behavior, init_cfg is not allowed to be set'
+        super().__init__()
+        _check(num_proposals == 3 and proposal_feature_channel == 256, 'FixedEmbeddingRPNHead: 3 queries (face, eyes, head) of 256 channels')
+        self.num_proposals, self.proposal_feature_channel = num_proposals, proposal_feature_channel
+        self.init_proposal_bboxes = nn.Embedding(num_proposals, 4)
+        self.init_proposal_features = nn.Embedding(num_proposals, proposal_feature_channel)
+
+    def init_weights(self):
+        nn.init.constant_(self.init_proposal_bboxes.weight[:, :2], 0.5)
+        nn.init.constant_(self.init_proposal_bboxes.weight[:, 2:], 1)
+
+
+@MODELS.register_module()
+class SingleRoIExtractor(_Holder):
+    def __init__(self, roi_layer, out_channels, featmap_strides, finest_scale=56, init_cfg=None):
+        super().__init__()
+        rl = dict(roi_layer)
+        _check(rl.pop('type') == 'RoIAlign', 'SingleRoIExtractor: roi_layer must be RoIAlign')
+        _check(rl.pop('output_size') in (7, (7, 7), [7, 7]) and rl.pop('sampling_ratio', 0) == 2, 'RoIAlign(output_size=7, sampling_ratio=2)')
+        _check(rl.pop('pool_mode', 'avg') == 'avg' and rl.pop('aligned', True) and not rl, 'RoIAlign: avg pooling, aligned=True')
+        _check(out_channels == 256 and list(featmap_strides) == [4, 8, 16, 32] and finest_scale == 56, 'strides [4,8,16,32], finest_scale 56')
+        self.out_channels, self.featmap_strides, self.finest_scale = out_channels, list(featmap_strides), finest_scale
+
+    @property
+    def num_inputs(self):
+        return len(self.featmap_strides)
+
+
+# ------------------------------------------------------------------------------------------------ decoder stage
+@TRANSFORMER.register_module()
+class DynamicConv(_Holder):
+    def __init__(self, in_channels=256, feat_channels=64, out_channels=None, input_feat_shape=7, with_proj=True,
+                 act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN'), init_cfg=None):
+        super().__init__()
+        out_channels = out_channels if out_channels else in_channels
+        _check(in_channels == 256 and feat_channels == 64 and out_channels == 256 and input_feat_shape == 7 and with_proj, 'DynamicConv: 256 -> 64 -> 256 on 7x7')
+        _check(act_cfg.get('type') == 'ReLU' and norm_cfg.get('type') == 'LN', 'DynamicConv: ReLU + LayerNorm')
+        self.in_channels, self.feat_channels, self.out_channels = in_channels, feat_channels, out_channels
+        self.dynamic_layer = nn.Linear(in_channels, in_channels * feat_channels + out_channels * feat_channels)
+        self.norm_in = nn.LayerNorm(feat_channels)
+        self.norm_out = nn.LayerNorm(out_channels)
+        self.fc_layer = nn.Linear(out_channels * input_feat_shape ** 2, out_channels)
+        self.fc_norm = nn.LayerNorm(out_channels)
+
+
+class _MultiheadAttention(nn.Module):
+    def __init__(self, embed_dims, num_heads, dropout):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, dropout)
+
+
+class _FFN(nn.Module):
+    def __init__(self, embed_dims, feedforward_channels, dropout):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(dropout)),
+                                    nn.Linear(feedforward_channels, embed_dims), nn.Dropout(dropout))
+
+
+def _tower(n, c):
+    layers = nn.ModuleList()
+    for _ in range(n):
+        layers.extend([nn.Linear(c, c, bias=False), nn.LayerNorm(c), nn.ReLU(inplace=True)])
+    return layers
+
+
+@MODELS.register_module()
+class GazeSTQIHead(_Holder):
+    def __init__(self, num_classes=80, num_ffn_fcs=2, num_heads=8, num_cls_fcs=1, num_reg_fcs=3, feedforward_channels=2048,
+                 in_channels=256, dropout=0.0, ffn_act_cfg=dict(type='ReLU', inplace=True),
+                 dynamic_conv_cfg=dict(type='DynamicConv', in_channels=256, feat_channels=64, out_channels=256, input_feat_shape=7,
+                                       act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN')),
+                 loss_iou=dict(type='GIoULoss', loss_weight=2.0), init_cfg=None,
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0), loss_bbox=dict(type='L1Loss', loss_weight=1.0),
+                 bbox_coder=dict(type='DeltaXYWHBBoxCoder', clip_border=True, target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2]),
+                 roi_feat_size=7, **kwargs):
+        assert init_cfg is None, 'To prevent abnormal initialization behavior, init_cfg is not allowed to be set'
+        super().__init__()
+        _check(in_channels == 256 and num_heads == 8 and num_ffn_fcs == 2 and feedforward_channels == 2048, 'GazeSTQIHead: d=256, 8 heads, FFN 2048')
+        _check(num_cls_fcs == 1 and num_reg_fcs == 3 and dropout == 0.0 and ffn_act_cfg.get('type') == 'ReLU', 'GazeSTQIHead: towers 1/3, dropout 0, ReLU')
+        self.num_classes, self.in_channels = num_classes, in_channels
+        self.reg_class_agnostic, self.reg_decoded_bbox = True, True
+        self.loss_cls, self.loss_bbox, self.loss_iou = build_loss(loss_cls), build_loss(loss_bbox), build_loss(loss_iou)
+        _check(self.loss_cls.use_sigmoid, 'GazeSTQIHead: loss_cls.use_sigmoid=True (sigmoid scores, 1 logit per clue)')
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        _check(not self.bbox_coder.clip_border and self.bbox_coder.means == (0., 0., 0., 0.), 'bbox_coder: clip_border=False, zero means')
+        # dead leftovers of BBoxHead.__init__ (bbox_head.py:72-81): kept so checkpoints load strictly
+        self.fc_cls = nn.Linear(in_channels * roi_feat_size ** 2, num_classes + 1)
+        self.fc_reg = nn.Linear(in_channels * roi_feat_size ** 2, 4)
+        self.attention = _MultiheadAttention(in_channels, num_heads, dropout)
+        self.attention_norm = nn.LayerNorm(in_channels)
+        self.instance_interactive_conv = build_transformer(dynamic_conv_cfg)
+        self.instance_interactive_conv_dropout = nn.Dropout(dropout)
+        self.instance_interactive_conv_norm = nn.LayerNorm(in_channels)
+        self.ffn = _FFN(in_channels, feedforward_channels, dropout)
+        self.ffn_norm = nn.LayerNorm(in_channels)
+        self.cls_fcs = _tower(num_cls_fcs, in_channels)
+        self.reg_fcs = _tower(num_reg_fcs, in_channels)
+        for c in CLUES:
+            setattr(self, f'{c}_fc_cls', nn.Linear(in_channels, 1))
+            setattr(self, f'{c}_fc_reg', nn.Linear(in_channels, 4))
+
+
+@MODELS.register_module()
+class GazeHead(_Holder):
+    def __init__(self, in_channels=256, gaze_dim=3, loss_gaze=None, loss_temp=None, **kwargs):
+        super().__init__()
+        _check(in_channels == 256 and gaze_dim == 3, 'GazeHead: 256 channels, 3-d gaze vectors')
+        self.in_channels, self.gaze_dim = in_channels, gaze_dim
+        self.loss_gaze = build_loss(loss_gaze) if loss_gaze else None
+        self.loss_temp = build_loss(loss_temp) if loss_temp else None
+        for c in CLUES:
+            setattr(self, f'gaze_{c}_fcs', _tower(2, in_channels))
+        for c in CLUES:
+            setattr(self, f'fc_{c}_confidence', nn.Linear(in_channels, gaze_dim))
+        for c in CLUES:
+            setattr(self, f'gaze_{c}_confidence', _tower(2, in_channels))
+        for c in CLUES:
+            setattr(self, f'fc_{c}', nn.Linear(in_channels, 3))
+        self.fc_gaze = nn.Linear(3 * 3, 3)
+
+
+@MODELS.register_module()
+class MultiClueGazeROIHead(_Holder):
+    def __init__(self, num_stages=6, stage_loss_weights=(1, 1, 1, 1, 1, 1), proposal_feature_channel=256, bbox_roi_extractor=None,
+                 mask_roi_extractor=None, bbox_head=None, mask_head=None, gaze_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, init_cfg=None):
+        super().__init__()
+        assert bbox_roi_extractor is not None and bbox_head is not None
+        assert len(stage_loss_weights) == num_stages
+        _check(mask_head is None and mask_roi_extractor is None, 'MultiClueGazeROIHead: no mask branch')
+        self.num_stages, self.stage_loss_weights = num_stages, stage_loss_weights
+        self.proposal_feature_channel, self.train_cfg, self.test_cfg = proposal_feature_channel, train_cfg, test_cfg
+        per_stage = lambda c: c if isinstance(c, (list, tuple)) else [c for _ in range(num_stages)]
+        assert len(per_stage(bbox_roi_extractor)) == len(per_stage(bbox_head)) == num_stages
+        self.bbox_roi_extractor = nn.ModuleList(build_roi_extractor(c) for c in per_stage(bbox_roi_extractor))
+        self.bbox_head = nn.ModuleList(build_head(c) for c in per_stage(bbox_head))
+        if gaze_head is not None:
+            assert len(per_stage(gaze_head)) == num_stages
+            self.gaze_head = nn.ModuleList(build_head(c) for c in per_stage(gaze_head))
+        stds = {tuple(h.bbox_coder.stds) for h in self.bbox_head}
+        _check(len(stds) == 1, 'all stages must share one bbox_coder.target_stds')
+        self.bbox_stds = stds.pop()
+
+    @property
+    def with_bbox(self):
+        return True
+
+    @property
+    def with_gaze(self):
+        return hasattr(self, 'gaze_head') and self.gaze_head is not None
+
+
+def bbox2result(bboxes, labels, num_classes):
+    """mmdet/core/bbox/transforms.py:116-133."""
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)]
+    if isinstance(bboxes, torch.Tensor):
+        bboxes = bboxes.detach().cpu().numpy()
+    labels = np.asarray(labels)
+    return [bboxes[labels == i, :] for i in range(num_classes)]
+
+
+# ------------------------------------------------------------------------------------------------ detector
+@MODELS.register_module()
+class MultiClueGaze(nn.Module):
+    """``model(img=[Tensor N x 3 x H x W], img_metas=[[dict]*N], return_loss=False, rescale=…, format=…)``
+    -> ``((det_bboxes: list[N] of Tensor[3,5], det_labels: list[N] of [0,1,2]), {gaze_score, face_gaze_score,
+    eyes_gaze_score, head_gaze_score: Tensor[N,3]})`` exactly as the reference's ``simple_test``.
+
+    Extension (the reference never batches clips at inference): pass
+    ``clip_length=T`` to treat the N frames as N/T independent clips (the semantics of the
+    reference's ``forward_train``); without it the N frames form ONE clip, as in the reference.
+    ``precision`` ('bf16' throughput engine | 'fp32' parity engine) is an attribute of the model."""
+
+    def __init__(self, backbone, rpn_head, roi_head, train_cfg, test_cfg, neck=None, pretrained=None, init_cfg=None):
+        super().__init__()
+        _check(neck is not None, 'MultiClueGaze needs the FPN neck')
+        if pretrained:
+            backbone = dict(backbone, pretrained=pretrained)
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck)
+        rpn_train_cfg = train_cfg.get('rpn') if train_cfg is not None else None
+        self.rpn_head = build_head(dict(rpn_head, train_cfg=rpn_train_cfg, test_cfg=(test_cfg or {}).get('rpn')))
+        rcnn_train_cfg = train_cfg.get('rcnn') if train_cfg is not None else None
+        self.roi_head = build_head(dict(roi_head, train_cfg=rcnn_train_cfg, test_cfg=(test_cfg or {}).get('rcnn'), pretrained=pretrained))
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.precision = 'bf16'
+        self.chunk_frames = 0
+        self._engine = None
+        self._engine_key = None
+
+    # -- properties of TwoStageDetector / BaseDetector the harness may query
+    with_neck = with_rpn = with_roi_head = with_bbox = True
+    with_mask = False
+
+    def init_weights(self):
+        for m in self.modules():
+            if m is not self and hasattr(m, 'init_weights'):
+                m.init_weights()
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._engine = None
+        return super().load_state_dict(state_dict, strict=strict)
+
+    def engine(self):
+        """The HIP engine for the current weights / precision / device (built on first use)."""
+        from .engine import HipEngine
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            from .lib import McgError
+            raise McgError('MultiClueGaze: move the model to a HIP device first (model.to("cuda:0")); mcgaze_amd has no CPU path')
+        key = (self.precision, str(dev))
+        if self._engine is None or self._engine_key != key:
+            self._engine = HipEngine(self.state_dict(), depth=self.backbone.depth, num_stages=self.roi_head.num_stages,
+                                     precision=self.precision, device=dev, bbox_stds=self.roi_head.bbox_stds)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        """mmdet/models/detectors/base.py:156-174."""
+        if return_loss:
+            raise NotImplementedError('MultiClueGaze.forward_train: training is outside the scope of mcgaze_amd (inference hot path only)')
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """mmdet/models/detectors/base.py:112-154 (argument checks and error behaviour kept)."""
+        for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError(f'{name} must be a list, but got {type(var)}')
+        num_augs = len(imgs)
+        if num_augs != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        if num_augs != 1:
+            raise NotImplementedError('aug_test is not supported for the gaze path (the reference has none either)')
+        for img, img_meta in zip(imgs, img_metas):
+            for img_id in range(len(img_meta)):
+                img_meta[img_id]['batch_input_shape'] = tuple(img.size()[-2:])
+        return self.simple_test(imgs[0], img_metas[0], **kwargs)
+
+    def simple_test(self, img, img_metas, rescale=False, format=False, clip_length=None):
+        """mmdet/models/detectors/multiclue_gaze.py:105-131 + multiclue_gaze_roi_head.py:287-384."""
+        N = img.size(0)
+        assert len(img_metas) == N, f'{N} frames but {len(img_metas)} img_metas'
+        T = N if clip_length is None else int(clip_length)
+        eng = self.engine()
+        x = img.to(device=eng.device, dtype=torch.float32).contiguous()
+        hw = np.array([m['img_shape'][:2] for m in img_metas], dtype=np.int32)
+        full = bool((hw[:, 0] == x.shape[2]).all() and (hw[:, 1] == x.shape[3]).all())
+        out = eng.forward(x, T, img_hw=None if full else hw, chunk_frames=self.chunk_frames)
+        boxes, scores, gaze = out['boxes'], out['scores'], out['gaze']
+        if rescale:
+            sf = torch.as_tensor(np.stack([np.asarray(m['scale_factor'], dtype=np.float32) for m in img_metas]), device=boxes.device)
+            boxes = boxes / sf[:, None, :]
+        det = torch.cat([boxes, scores[..., None]], dim=-1)
+        det_bboxes = [det[i] for i in range(N)]
+        det_labels = [[0, 1, 2] for _ in range(N)]
+        if format:
+            bbox_results = [bbox2result(det_bboxes[i], det_labels[i], self.roi_head.bbox_head[-1].num_classes) for i in range(N)]
+        else:
+            bbox_results = (det_bboxes, det_labels)
+        gaze_results = dict(gaze_score=gaze[0], face_gaze_score=gaze[1], eyes_gaze_score=gaze[2], head_gaze_score=gaze[3])
+        return bbox_results, gaze_results

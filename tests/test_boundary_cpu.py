@@ -1,0 +1,142 @@
+"""The drop-in boundary on CPU (-m "not gpu"): config loader, registry, module surface with the
+reference's state_dict layout, loud failure without a GPU, and that libmcgaze_hip.so loads and
+exports every symbol include/mcgaze_hip.h declares (no compute calls here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import mcgaze_amd
+from mcgaze_amd import Config, build_detector, synth
+from mcgaze_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OWN_CFG = os.path.join(ROOT, 'configs', 'mcgaze', 'r50_clip7_gaze360.py')
+REF_CFGS = ['/root/reference/configs/multiclue_gaze/multiclue_gaze_r50_gaze360.py',
+            '/root/reference/configs/multiclue_gaze/multiclue_gaze_r50_l2cs.py']
+
+
+def build(cfg_path):
+    cfg = Config.fromfile(cfg_path)
+    cfg.model.train_cfg = None
+    if 'init_cfg' in cfg.model.backbone:
+        cfg.model.backbone.init_cfg = None
+    return cfg, build_detector(cfg.model)
+
+
+def test_own_config_builds_reference_state_dict_layout():
+    cfg, model = build(OWN_CFG)
+    assert cfg.clip_length == 7 and cfg.data.test.pipeline[1].type == 'CenterCrop' and cfg.dist_params.backend == 'nccl'
+    ref = synth.make_state_dict(0)
+    sd = model.state_dict()
+    assert set(sd) == set(ref) and len(sd) == 744
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(np.asarray(ref[k]).shape), k
+    assert sum(v.numel() for v in sd.values()) == 83367453  # SURVEY.md section 0 [probe]
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}, strict=True)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFGS[0]), reason='reference tree only exists in the build container')
+@pytest.mark.parametrize('path', REF_CFGS)
+def test_reference_configs_load_unchanged(path):
+    cfg = Config.fromfile(path)
+    # _base_ chain + _delete_ semantics (multiclue_gaze_r50_gaze360.py:100-112)
+    assert cfg.optimizer.type == 'AdamW' and 'momentum' not in cfg.optimizer
+    assert cfg.runner == dict(type='IterBasedRunner', max_iters=7000 if 'gaze360.py' in path else 13000)
+    assert cfg.lr_config.warmup == 'linear' and cfg.lr_config.warmup_iters == 1000  # merged, not replaced
+    assert len(cfg.model.roi_head.bbox_head) == 4 and cfg.model.roi_head.bbox_head[0].bbox_coder.target_stds == [0.5, 0.5, 1., 1.]
+    if 'l2cs' in path:
+        assert cfg.data.test.pipeline[1].img_scale == (448, 448) and cfg.data.samples_per_gpu == 8
+    for with_train_cfg in (True, False):  # train_cfg names assigner/sampler types that must at least parse
+        c = Config.fromfile(path)
+        c.model.backbone.init_cfg = None
+        if not with_train_cfg:
+            c.model.train_cfg = None
+        model = build_detector(c.model)
+        assert set(model.state_dict()) == set(synth.make_state_dict(0))
+
+
+def test_cfg_options_merge():
+    cfg = Config.fromfile(OWN_CFG)
+    cfg.merge_from_dict({'model.roi_head.num_stages': 4, 'data.samples_per_gpu': 8, 'new.key': 1})
+    assert cfg.data.samples_per_gpu == 8 and cfg.new.key == 1 and cfg.model.neck.out_channels == 256
+
+
+def test_registry_semantics():
+    from mcgaze_amd.registry import Registry, build_from_cfg
+    reg = Registry('toy')
+
+    @reg.register_module()
+    class A:
+        def __init__(self, x, y=2):
+            self.x, self.y = x, y
+    assert reg.build(dict(type='A', x=1)).y == 2 and build_from_cfg(dict(type=A, x=3), reg, dict(y=5)).y == 5
+    with pytest.raises(KeyError):
+        reg.build(dict(type='Missing'))
+    with pytest.raises(KeyError):
+        reg.register_module(module=A)
+    assert mcgaze_amd.MODELS.get('MultiClueGaze') is not None and mcgaze_amd.TRANSFORMER.get('DynamicConv') is not None
+    assert mcgaze_amd.BACKBONES is mcgaze_amd.HEADS is mcgaze_amd.DETECTORS
+
+
+def test_unsupported_options_fail_loudly():
+    cfg = Config.fromfile(OWN_CFG)
+    cfg.model.backbone.style = 'caffe'
+    with pytest.raises(NotImplementedError):
+        build_detector(cfg.model)
+    cfg = Config.fromfile(OWN_CFG)
+    cfg.model.backbone.depth = 18
+    with pytest.raises(KeyError):
+        build_detector(cfg.model)
+
+
+def test_forward_argument_errors_and_no_cpu_fallback():
+    _, model = build(OWN_CFG)
+    img = torch.zeros(7, 3, 224, 224)
+    metas = synth.make_img_metas(7)
+    with pytest.raises(TypeError):          # base.py:122-124
+        model(img=img, img_metas=[metas], return_loss=False)
+    with pytest.raises(ValueError):         # base.py:127-129
+        model(img=[img, img], img_metas=[metas], return_loss=False)
+    with pytest.raises(NotImplementedError):
+        model(img=[img], img_metas=[metas], return_loss=True)
+    if not torch.cuda.is_available():
+        with pytest.raises(L.McgError):     # the product path refuses to run without the HIP device
+            model(img=[img], img_metas=[metas], return_loss=False)
+        with pytest.raises(RuntimeError):
+            model.backbone(img)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'mcgaze_hip.h')).read()
+    declared = set(re.findall(r'\b(mcg_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'mcg_stream', 'mcg_dtype'}
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    lib = L.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert lib.mcg_abi_version() == 1
+    assert L.SW_COUNT == 34 and L.GW_COUNT == 7
+
+
+def test_dyn_permutation_matches_reference_view():
+    """params[:, :d*f].view(d, f) / params[:, -d*f:].view(f, d) (transformer.py:1134-1137) -> K-contiguous rows."""
+    from mcgaze_amd.packing import dyn_permutation
+    d, f = 256, 64
+    theta = torch.arange(2 * d * f, dtype=torch.float32)
+    w_in, w_out = theta[:d * f].view(d, f), theta[-d * f:].view(f, d)
+    p = theta[dyn_permutation(d, f)]
+    assert torch.equal(p[:d * f].view(f, d), w_in.t()) and torch.equal(p[d * f:].view(d, f), w_out.t())
+
+
+def test_bn_fold_equals_conv_then_bn():
+    from mcgaze_amd.packing import fold_bn
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(1).items() if k.startswith('backbone.layer1.0.')}
+    x = torch.randn(2, 64, 9, 9)
+    w, b = fold_bn(sd, 'backbone.layer1.0.conv1.weight', 'backbone.layer1.0.bn1')
+    ref = torch.nn.functional.batch_norm(torch.nn.functional.conv2d(x, sd['backbone.layer1.0.conv1.weight']),
+                                         sd['backbone.layer1.0.bn1.running_mean'], sd['backbone.layer1.0.bn1.running_var'],
+                                         sd['backbone.layer1.0.bn1.weight'], sd['backbone.layer1.0.bn1.bias'], False, 0., 1e-5)
+    assert torch.allclose(torch.nn.functional.conv2d(x, w, b), ref, atol=1e-5)

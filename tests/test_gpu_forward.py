@@ -129,3 +129,30 @@ def test_errors_are_loud(engines):
         e.forward(torch.zeros(6, 3, 224, 224, device='cuda:0'), 7)      # N not a multiple of clip_length
     with pytest.raises(McgError):
         e.forward(torch.zeros(7, 3, 100, 224, device='cuda:0'), 7)      # H not a multiple of 32
+
+
+def test_registry_surface_reproduces_reference_outputs(golden_dir):
+    """The drop-in boundary end to end: config -> init_detector -> model(return_loss=False, ...) returns the
+    reference's output structure and values (fp32 engine) for single clips, and for a batch via clip_length."""
+    from mcgaze_amd import init_detector
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = init_detector(os.path.join(root, 'configs', 'mcgaze', 'r50_clip7_gaze360.py'), None, device='cuda:0', precision='fp32')
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(0).items()}, strict=True)
+    assert model.CLASSES == ('face', 'eyes', 'head') and model.cfg.clip_length == 7
+    for name in ('clip224', 'clip_nonsquare', 'batch2'):
+        g, img, B, T, ishape = load_case(golden_dir, name)
+        pshape = tuple(int(v) for v in g['pad_shape'])
+        metas = synth.make_img_metas(B * T, ishape, pshape, tuple(float(v) for v in g['scale_factor']))
+        kw = dict(clip_length=T) if B > 1 else {}
+        with torch.no_grad():
+            (det_bboxes, det_labels), gaze = model(img=[torch.from_numpy(img)], img_metas=[metas], return_loss=False,
+                                                   rescale=bool(g['rescale']), format=False, **kw)
+        assert len(det_bboxes) == B * T and all(tuple(d.shape) == (3, 5) for d in det_bboxes) and det_labels[0] == [0, 1, 2]
+        assert set(gaze) == set(KEYS) and all(tuple(v.shape) == (B * T, 3) and v.is_cuda for v in gaze.values())
+        for k in KEYS:
+            assert (orc.yaw_pitch(gaze[k].cpu()) - orc.yaw_pitch(g[k])).abs().max().item() < F32_TOL
+        np.testing.assert_allclose(torch.stack(det_bboxes).cpu().numpy(), g['det_bboxes'], atol=5e-2, rtol=1e-4)
+    # format=True goes through bbox2result: per-frame list of per-class arrays
+    g, img, B, T, ishape = load_case(golden_dir, 'clip224')
+    res, _ = model(img=[torch.from_numpy(img)], img_metas=[synth.make_img_metas(T)], return_loss=False, rescale=False, format=True)
+    assert len(res) == T and len(res[0]) == 3 and res[0][0].shape == (1, 5)
