@@ -88,6 +88,15 @@ static void launch_dma(hipStream_t s, const IgemmParams& p, int groups) {
   hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, BKB, WM, WN, ST>), grid, dim3(64 * WM * WN), 0, s, p);
 }
 
+// The DMA kernel addresses both operands through 2 GiB buffer descriptors with 32-bit offsets and keeps the
+// in-image tap mask in 32 bits; anything larger falls back to the register-staged kernel (64-bit pointers).
+static bool dma_eligible(const IgemmParams& p, int es) {
+  const long long frames = p.M / ((long long)p.Ho * p.Wo);
+  const long long x_extent = ((frames - 1) * p.xs_n + (long long)(p.H - 1) * p.xs_h + (long long)(p.W - 1) * p.xs_w + p.Cin) * es;
+  const long long w_extent = (long long)p.Cout * p.KH * p.KW * p.Cin * es;
+  return x_extent > 0 && x_extent < MCG_DMA_MAX_BYTES && w_extent < MCG_DMA_MAX_BYTES && (p.nocheck || p.KH * p.KW <= 32);
+}
+
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -99,7 +108,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   // tuning knobs (experiments): MCG_IGEMM=1 selects the register-staged kernel for bf16 too,
   // MCG_FORCE_NARROW=1 its 64-byte K slices, MCG_TILE=1 the 256x128 DMA tile.
   static const int use_v1 = env_int("MCG_IGEMM", 0), force_narrow = env_int("MCG_FORCE_NARROW", 0), big_tile = env_int("MCG_TILE", -1);
-  const bool dma = ES == 2 && !use_v1;
+  const bool dma = ES == 2 && !use_v1 && dma_eligible(p, ES);
   const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0;
   MCG_CHECK_ARG((p.Cin * ES) % 64 == 0, "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
   MCG_CHECK_ARG(p.Cout % (16 / ES) == 0, "igemm: Cout=%d must be a multiple of %d", p.Cout, 16 / ES);
@@ -203,6 +212,7 @@ extern "C" int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d) {
     p.rscale_h = (float)d->Hr / (float)p.Ho;  // torch nearest: src = min(floor(dst * in/out), in-1)
     p.rscale_w = (float)d->Wr / (float)p.Wo;
   }
+  p.nocheck = d->pad == 0 ? 1 : 0;  // without padding every tap of every output pixel is inside the image
   p.splitk = 1; p.tiles_per_slice = 1 << 30;
   return launch_igemm((hipStream_t)s, dt, p, 1);
 }

@@ -1,0 +1,24 @@
+"""GPU tool: time one conv shape through mcg_conv2d.  usage: conv_bench.py N H W Cin Cout k stride pad [iters] [residual]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mcgaze_amd import engine as E
+N, H, W, Cin, Cout, k, stride, pad = [int(v) for v in sys.argv[1:9]]
+iters = int(sys.argv[9]) if len(sys.argv) > 9 else 20
+res = int(sys.argv[10]) if len(sys.argv) > 10 else 0
+dt = torch.bfloat16
+x = torch.randn(N, H, W, Cin, device='cuda').to(dt)
+w = (torch.randn(Cout, k, k, Cin, device='cuda') / (Cin * k * k) ** 0.5).to(dt)
+b = torch.randn(Cout, device='cuda')
+Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+r = torch.randn(N, Ho, Wo, Cout, device='cuda').to(dt) if res else None
+for _ in range(3):
+    y = E.conv2d(x, w, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1 if res else 0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(iters):
+    y = E.conv2d(x, w, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1 if res else 0)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / iters * 1e3
+fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
+print(f'conv N={N} {H}x{W} {Cin}->{Cout} k{k} s{stride}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TF/s  (MCG_TILE={os.environ.get("MCG_TILE", "auto")})')
