@@ -64,6 +64,12 @@ typedef struct {
   int relu;             /* 1: y = max(y, 0) after bias and residual                 */
   int residual_mode;    /* MCG_RES_*                                                */
   int Hr, Wr;           /* residual spatial size for UPSAMPLE_ADD (nearest, F.interpolate size=) */
+  /* Optional second input, K-concatenated after the first (needs KH=KW=1, stride 1, pad 0):
+   *   y = [x | x2 sampled at stride2] . [w1 | w2]^T,  w = [Cout][Cin + Cin2].
+   * Fuses a bottleneck's conv3 with its downsample conv (mmdet/models/utils/res_layer.py:51-61,
+   * resnet.py:289-298): x2 = the block input, w2 = the BN-folded downsample weight. */
+  const void* x2;       /* NHWC [N,H2,W2,Cin2] or NULL */
+  int Cin2, stride2, H2, W2;
 } mcg_conv_desc;
 int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);
 
@@ -151,6 +157,7 @@ typedef struct {
   int num_convs;
   mcg_conv_weights lateral[4];
   mcg_conv_weights fpn_out[4];
+  mcg_conv_weights c3_ds[4];        /* per layer: first block's conv3 and downsample fused ([Cout][planes + inplanes], bias summed); w = NULL -> unfused */
   const float* init_boxes;          /* f32 [3][4] normalised cxcywh (rpn_head.init_proposal_bboxes.weight) */
   const void* init_feats;           /* dtype [3][256] */
   int num_stages;

@@ -19,7 +19,7 @@ struct mcg_engine {
   int blocks[4];
   mcg_conv_weights stem;
   std::vector<mcg_conv_weights> convs;
-  mcg_conv_weights lateral[4], fpn_out[4];
+  mcg_conv_weights lateral[4], fpn_out[4], c3_ds[4];
   const float* init_boxes;
   const void* init_feats;
   int num_stages;
@@ -48,6 +48,7 @@ extern "C" int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, m
   e->convs.assign(w->convs, w->convs + w->num_convs);
   memcpy(e->lateral, w->lateral, sizeof(e->lateral));
   memcpy(e->fpn_out, w->fpn_out, sizeof(e->fpn_out));
+  memcpy(e->c3_ds, w->c3_ds, sizeof(e->c3_ds));
   e->init_boxes = w->init_boxes;
   e->init_feats = w->init_feats;
   e->num_stages = w->num_stages;
@@ -117,13 +118,25 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
       const int ho = (h + 2 * c2.pad - c2.k) / c2.stride + 1, wo = (w + 2 * c2.pad - c2.k) / c2.stride + 1;
       MCG_TRY(conv_call(s, dt, c1, x, n, h, w, t.o1, 1, nullptr, MCG_RES_NONE, 0, 0));
       MCG_TRY(conv_call(s, dt, c2, t.o1, n, h, w, t.o2, 1, nullptr, MCG_RES_NONE, 0, 0));
-      const void* identity = x;
-      if (has_ds) {
-        MCG_TRY(conv_call(s, dt, e->convs[ci + 3], x, n, h, w, t.ds, 0, nullptr, MCG_RES_NONE, 0, 0));
-        identity = t.ds;
-      }
       void* y = (b == e->blocks[l] - 1) ? (void*)t.c[l] : (x == t.xa ? (void*)t.xb : (void*)t.xa);
-      MCG_TRY(conv_call(s, dt, c3, t.o2, n, ho, wo, y, 1, identity, MCG_RES_ADD, 0, 0));
+      if (has_ds && e->c3_ds[l].w) {
+        // conv3 and the downsample conv as ONE K-concatenated GEMM: relu([o2 | x@stride] . [W3 | Wd]^T + b3 + bd);
+        // the downsample output never goes to HBM and conv3 reads no residual.
+        const mcg_conv_weights& f = e->c3_ds[l];
+        mcg_conv_desc d;
+        memset(&d, 0, sizeof(d));
+        d.x = t.o2; d.w = f.w; d.bias = f.bias; d.y = y;
+        d.N = n; d.H = ho; d.W = wo; d.Cin = c3.cin; d.Cout = c3.cout; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0; d.relu = 1;
+        d.x2 = x; d.Cin2 = e->convs[ci + 3].cin; d.stride2 = e->convs[ci + 3].stride; d.H2 = h; d.W2 = w;
+        MCG_TRY(mcg_conv2d(s, dt, &d));
+      } else {
+        const void* identity = x;
+        if (has_ds) {
+          MCG_TRY(conv_call(s, dt, e->convs[ci + 3], x, n, h, w, t.ds, 0, nullptr, MCG_RES_NONE, 0, 0));
+          identity = t.ds;
+        }
+        MCG_TRY(conv_call(s, dt, c3, t.o2, n, ho, wo, y, 1, identity, MCG_RES_ADD, 0, 0));
+      }
       x = y; h = ho; w = wo;
       ci += has_ds ? 4 : 3;
     }

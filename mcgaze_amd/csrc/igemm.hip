@@ -93,7 +93,11 @@ static void launch_dma(hipStream_t s, const IgemmParams& p, int groups) {
 static bool dma_eligible(const IgemmParams& p, int es) {
   const long long frames = p.M / ((long long)p.Ho * p.Wo);
   const long long x_extent = ((frames - 1) * p.xs_n + (long long)(p.H - 1) * p.xs_h + (long long)(p.W - 1) * p.xs_w + p.Cin) * es;
-  const long long w_extent = (long long)p.Cout * p.KH * p.KW * p.Cin * es;
+  const long long w_extent = (long long)p.Cout * ((long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0)) * es;
+  if (p.x2) {
+    const long long x2_extent = ((frames - 1) * p.xs2_n + (long long)(p.Ho - 1) * p.stride2 * p.xs2_h + (long long)(p.Wo - 1) * p.stride2 * p.xs2_w + p.Cin2) * es;
+    if (x2_extent >= MCG_DMA_MAX_BYTES) return false;
+  }
   return x_extent > 0 && x_extent < MCG_DMA_MAX_BYTES && w_extent < MCG_DMA_MAX_BYTES && (p.nocheck || p.KH * p.KW <= 32);
 }
 
@@ -109,8 +113,8 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   // MCG_FORCE_NARROW=1 its 64-byte K slices, MCG_TILE=1 the 256x128 DMA tile.
   static const int use_v1 = env_int("MCG_IGEMM", 0), force_narrow = env_int("MCG_FORCE_NARROW", 0), big_tile = env_int("MCG_TILE", -1);
   const bool dma = ES == 2 && !use_v1 && dma_eligible(p, ES);
-  const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0;
-  MCG_CHECK_ARG((p.Cin * ES) % 64 == 0, "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
+  const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0 && (!p.x2 || (p.Cin2 * ES) % 128 == 0);
+  MCG_CHECK_ARG((p.Cin * ES) % 64 == 0 && (!p.x2 || (p.Cin2 * ES) % 64 == 0), "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
   MCG_CHECK_ARG(p.Cout % (16 / ES) == 0, "igemm: Cout=%d must be a multiple of %d", p.Cout, 16 / ES);
   // DMA tile choice (profiles/r01_b_tile_sweep.md): 0 = 128x128 4 waves 4 stages, 1 = 256x128 4 waves,
   // 3 = 256x256 8 waves, 5 = 256x128 8 waves with 128-byte K slices.  MCG_TILE >= 0 overrides (experiments).
@@ -120,15 +124,15 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     if (big_tile >= 0) tile = big_tile;
     else if (p.Cout <= 128) tile = Kdim >= 1024 ? 1 : 0;
     else if (p.M >= 300000) tile = 3;
-    else if (p.M >= 80000) tile = p.Cout >= 512 ? 3 : ((p.Cin * ES) % 128 == 0 ? 5 : 1);
+    else if (p.M >= 80000) tile = p.Cout >= 512 ? 3 : (((p.Cin * ES) % 128 == 0 && !p.x2) ? 5 : 1);
     else tile = 1;
   }
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
   ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
   if (rec) {
     rec->cfg = cfg;
-    rec->shape[0] = p.M; rec->shape[1] = p.Cout * groups; rec->shape[2] = p.KH * p.KW * p.Cin;
-    rec->flops = 2.0 * p.M * p.Cout * (p.algo_k > 0 ? (double)p.algo_k : (double)p.KH * p.KW * p.Cin) * groups;
+    rec->shape[0] = p.M; rec->shape[1] = p.Cout * groups; rec->shape[2] = p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
+    rec->flops = 2.0 * p.M * p.Cout * (p.algo_k > 0 ? (double)p.algo_k : (double)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0)) * groups;
     (void)hipEventRecord(rec->a, s);
   }
   if (dma) {
@@ -136,8 +140,8 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     else if (tile == 1) launch_dma<T, 256, 128, 64, 2, 2, 3>(s, p, groups);
     else if (tile == 2) launch_dma<T, 256, 128, 64, 4, 2, 3>(s, p, groups);
     else if (tile == 3) launch_dma<T, 256, 256, 64, 4, 2, 3>(s, p, groups);
-    else if (tile == 4 && (p.Cin * ES) % 128 == 0) launch_dma<T, 128, 128, 128, 2, 2, 3>(s, p, groups);
-    else if (tile == 5 && (p.Cin * ES) % 128 == 0) launch_dma<T, 256, 128, 128, 4, 2, 3>(s, p, groups);
+    else if (tile == 4 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 128, 128, 128, 2, 2, 3>(s, p, groups);
+    else if (tile == 5 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 128, 128, 4, 2, 3>(s, p, groups);
     else launch_dma<T, 128, 128, 64, 2, 2, 4>(s, p, groups);
   } else if (p.Cout <= 64) {
     if (wide) launch_cfg<T, 128, 64, 128, 4, 1>(s, p, groups);
@@ -213,6 +217,12 @@ extern "C" int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d) {
     p.rscale_w = (float)d->Wr / (float)p.Wo;
   }
   p.nocheck = d->pad == 0 ? 1 : 0;  // without padding every tap of every output pixel is inside the image
+  if (d->x2) {
+    MCG_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->pad == 0 && d->stride == 1, "mcg_conv2d: a second source needs a 1x1 / stride 1 / pad 0 primary conv");
+    MCG_CHECK_ARG(d->Cin2 > 0 && d->stride2 >= 1 && d->H2 >= (p.Ho - 1) * d->stride2 + 1 && d->W2 >= (p.Wo - 1) * d->stride2 + 1, "mcg_conv2d: second source geometry");
+    p.x2 = d->x2; p.Cin2 = d->Cin2; p.stride2 = d->stride2;
+    p.xs2_w = d->Cin2; p.xs2_h = (long long)d->W2 * d->Cin2; p.xs2_n = (long long)d->H2 * d->W2 * d->Cin2;
+  }
   p.splitk = 1; p.tiles_per_slice = 1 << 30;
   return launch_igemm((hipStream_t)s, dt, p, 1);
 }

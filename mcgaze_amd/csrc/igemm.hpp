@@ -31,6 +31,12 @@ struct IgemmParams {
   long long x_g, w_g, y_g, res_g;  // per-group element offsets (blockIdx.z)
   int bias_g;
   int splitk, tiles_per_slice;
+  // optional second A source, K-concatenated after the first (1x1 taps only): D = [A1 | A2] . [W1 | W2]^T.
+  // Used to fuse a bottleneck's conv3 with its downsample conv (res_layer.py:51-61): A2 = block input sampled at stride2.
+  const void* x2;
+  int Cin2, stride2;
+  long long xs2_n, xs2_h;
+  int xs2_w;
   int algo_k;  // algorithmic K for FLOP accounting when the packed K carries zero padding (stem); 0 = KH*KW*Cin
 };
 
@@ -60,15 +66,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   const T* __restrict__ X = (const T*)p.x + (long long)g * p.x_g;
   const T* __restrict__ Wt = (const T*)p.w + (long long)g * p.w_g;
-  const long long K = (long long)p.KH * p.KW * p.Cin;
+  const T* __restrict__ X2 = (const T*)p.x2;
+  const long long K = (long long)p.KH * p.KW * p.Cin + (X2 ? p.Cin2 : 0);
   const int tiles_per_tap = p.Cin / BK;
-  const int KT = p.KH * p.KW * tiles_per_tap;
+  const int KT1 = p.KH * p.KW * tiles_per_tap;
+  const int KT = KT1 + (X2 ? p.Cin2 / BK : 0);
   const int kt_begin = slice * p.tiles_per_slice;
   const int kt_end = min(KT, kt_begin + p.tiles_per_slice);
 
   // ---- per-thread staging coordinates
   const int chunk = tid % CPR, row_in_pass = tid / CPR;
-  long long a_off[A_ITERS];
+  long long a_off[A_ITERS], a_off2[A_ITERS];
   int a_hi0[A_ITERS], a_wi0[A_ITERS];
   int a_lds[A_ITERS], b_lds[B_ITERS];
   long long b_off[B_ITERS];
@@ -84,10 +92,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       a_hi0[it] = ho * p.stride - p.pad;
       a_wi0[it] = wo * p.stride - p.pad;
       a_off[it] = (long long)n * p.xs_n + (long long)a_hi0[it] * p.xs_h + (long long)a_wi0[it] * p.xs_w + chunk * EPC;
+      a_off2[it] = (long long)n * p.xs2_n + (long long)(ho * p.stride2) * p.xs2_h + (long long)(wo * p.stride2) * p.xs2_w + chunk * EPC;
     } else {
       a_hi0[it] = -(1 << 28);  // never valid
       a_wi0[it] = 0;
       a_off[it] = 0;
+      a_off2[it] = 0;
     }
   }
 #pragma unroll
@@ -100,14 +110,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   uint4 ra[A_ITERS], rb[B_ITERS];
   auto load_tile = [&](int kt) {
-    const int tap = kt / tiles_per_tap, c0 = (kt - tap * tiles_per_tap) * BK;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const long long tap_off = (long long)kh * p.xs_h + (long long)kw * p.xs_w + c0;
+    if (kt < KT1) {
+      const int tap = kt / tiles_per_tap, c0 = (kt - tap * tiles_per_tap) * BK;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      const long long tap_off = (long long)kh * p.xs_h + (long long)kw * p.xs_w + c0;
 #pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      const int hi = a_hi0[it] + kh, wi = a_wi0[it] + kw;
-      const bool ok = p.nocheck ? (a_hi0[it] > -(1 << 27)) : ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
-      ra[it] = ok ? *(const uint4*)(X + a_off[it] + tap_off) : make_uint4(0, 0, 0, 0);
+      for (int it = 0; it < A_ITERS; ++it) {
+        const int hi = a_hi0[it] + kh, wi = a_wi0[it] + kw;
+        const bool ok = p.nocheck ? (a_hi0[it] > -(1 << 27)) : ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W);
+        ra[it] = ok ? *(const uint4*)(X + a_off[it] + tap_off) : make_uint4(0, 0, 0, 0);
+      }
+    } else {  // second source: 1x1, always in range
+      const long long c0 = (long long)(kt - KT1) * BK;
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it)
+        ra[it] = (a_hi0[it] > -(1 << 27)) ? *(const uint4*)(X2 + a_off2[it] + c0) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it)

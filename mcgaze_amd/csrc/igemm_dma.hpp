@@ -95,13 +95,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(co
   const int g = blockIdx.z, slice = blockIdx.y;
 
   const int tiles_per_tap = p.Cin / BK;
-  const int KT = p.KH * p.KW * tiles_per_tap;
+  const int KT1 = p.KH * p.KW * tiles_per_tap;
+  const int KT = KT1 + (p.x2 ? p.Cin2 / BK : 0);  // optional K-concatenated second A source (1x1 taps)
   const int kt_begin = slice * p.tiles_per_slice;
   const int kt_end = min(KT, kt_begin + p.tiles_per_slice);
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int HoWo = p.Ho * p.Wo;
   const u32x4 srd_a = make_srd((const T*)p.x + (long long)g * p.x_g);
   const u32x4 srd_b = make_srd((const T*)p.w + (long long)g * p.w_g);
+  const u32x4 srd_a2 = make_srd(p.x2 ? p.x2 : p.x);
 
   // ---- residual prefetch for epilogue pass 0 (latency hidden under the K loop)
   const T* __restrict__ R = (const T*)p.res + (long long)g * p.res_g;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(co
 
   // ---- per-lane DMA source offsets (bytes, loop-invariant) and in-image tap masks
   const int drow = lane / CPR, dcs = lane % CPR;
-  uint32_t a_voff[A_PIECES], a_mask[A_PIECES], b_voff[B_PIECES];
+  uint32_t a_voff[A_PIECES], a_voff2[A_PIECES], a_mask[A_PIECES], b_voff[B_PIECES];
   const int chk = p.nocheck ? 0 : 1;
 #pragma unroll
   for (int i = 0; i < A_PIECES; ++i) {
@@ -147,8 +149,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(co
           if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W) mask |= 1u << (kh * p.KW + kw);
     }
     a_mask[i] = mask;
+    a_voff2[i] = (uint32_t)(((long long)n * p.xs2_n + (long long)(ho * p.stride2) * p.xs2_h + (long long)(wo * p.stride2) * p.xs2_w + chunk * EPC) * ES);
   }
-  const long long K = (long long)p.KH * p.KW * p.Cin;
+  const long long K = (long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
 #pragma unroll
   for (int i = 0; i < B_PIECES; ++i) {
     const int row = (wave * B_PIECES + i) * RPP + drow;
@@ -174,7 +177,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(co
   };
   auto issue_piece = [&](int q) {
     if (q < A_PIECES) {
-      if (chk) {  // padded conv: fold the tap into the per-lane offset (exact mod 2^32), zero-fill out-of-image taps
+      if (nk_t >= KT1) {  // second source (1x1): pure scalar K offset
+        lds_dma16(a_voff2[q], srd_a2, (uint32_t)(nk_t - KT1) * BKB, is_dst + (wave * A_PIECES + q) * 1024);
+      } else if (chk) {  // padded conv: fold the tap into the per-lane offset (exact mod 2^32), zero-fill out-of-image taps
         const uint32_t v = (a_mask[q] & is_tap_bit) ? a_voff[q] + is_tap_bytes : MCG_OOB_OFFSET;
         lds_dma16(v, srd_a, 0u, is_dst + (wave * A_PIECES + q) * 1024);
       } else {    // 1x1 / pre-padded / linear: the tap is a pure scalar offset
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(co
   auto issue_end = [&]() {
     if (nk_t + 1 < kt_end) {  // prefetches beyond the last K-tile simply re-read it
       ++nk_t;
-      if (++nk_c == tiles_per_tap) {
+      if (nk_t < KT1 && ++nk_c == tiles_per_tap) {
         nk_c = 0;
         ++nk_tap;
         if (++nk_kw == p.KW) { nk_kw = 0; ++nk_kh; }

@@ -56,18 +56,21 @@ def to_nchw(x_nhwc):
     return out
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual_mode=L.RES_NONE):
-    """x NHWC, w OHWI (same dtype), bias f32 -> NHWC.  mcg_conv2d."""
+def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual_mode=L.RES_NONE, x2=None, stride2=1):
+    """x NHWC, w OHWI (same dtype), bias f32 -> NHWC.  mcg_conv2d.  With x2: w = [Cout,1,1,Cin+Cin2], x2 sampled at stride2."""
     _require_gpu()
     lib = L.load()
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
+    Cin2 = x2.shape[3] if x2 is not None else 0
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     y = torch.empty(N, Ho, Wo, Cout, dtype=x.dtype, device=x.device)
     d = L.ConvDesc(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
                    residual.data_ptr() if residual is not None else None, y.data_ptr(),
                    N, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), residual_mode if residual is not None else L.RES_NONE,
-                   residual.shape[1] if residual is not None else 0, residual.shape[2] if residual is not None else 0)
+                   residual.shape[1] if residual is not None else 0, residual.shape[2] if residual is not None else 0,
+                   x2.data_ptr() if x2 is not None else None, Cin2, stride2, x2.shape[1] if x2 is not None else 0,
+                   x2.shape[2] if x2 is not None else 0)
     L.check(lib.mcg_conv2d(_stream(), _code(x.dtype), C.byref(d)), 'mcg_conv2d')
     return y
 
@@ -139,13 +142,14 @@ def gaze_head(gaze_w, obj):
 class HipEngine:
     """The whole per-clip forward path behind one C call (mcg_clip_forward)."""
 
-    def __init__(self, state_dict, depth=50, num_stages=4, precision='bf16', device='cuda:0', bbox_stds=(0.5, 0.5, 1.0, 1.0)):
+    def __init__(self, state_dict, depth=50, num_stages=4, precision='bf16', device='cuda:0', bbox_stds=(0.5, 0.5, 1.0, 1.0), fuse_downsample=True):
         _require_gpu()
         self.lib = L.load()
         self.device = torch.device(device)
         self.dtype = _TORCH_DT[precision]
         self.precision = precision
-        self.weights = PackedWeights(state_dict, depth=depth, num_stages=num_stages, dtype=self.dtype, device=self.device)
+        self.weights = PackedWeights(state_dict, depth=depth, num_stages=num_stages, dtype=self.dtype, device=self.device,
+                                     fuse_downsample=fuse_downsample)
         w = self.weights
         mk = lambda c: L.ConvWeights(c['w'].data_ptr(), c['bias'].data_ptr(), c['cin'], c['cout'], c['k'], c['stride'], c['pad'])
         self._convs = (L.ConvWeights * len(w.convs))(*[mk(c) for c in w.convs])
@@ -158,6 +162,8 @@ class HipEngine:
         mw.num_convs = len(w.convs)
         mw.lateral = (L.ConvWeights * 4)(*[mk(c) for c in w.lateral])
         mw.fpn_out = (L.ConvWeights * 4)(*[mk(c) for c in w.fpn_out])
+        if len(w.c3_ds) == 4:
+            mw.c3_ds = (L.ConvWeights * 4)(*[mk(c) for c in w.c3_ds])
         mw.init_boxes = w.init_boxes.data_ptr()
         mw.init_feats = w.init_feats.data_ptr()
         mw.num_stages = num_stages

@@ -33,7 +33,8 @@ class ConvDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('bias', C.c_void_p), ('residual', C.c_void_p), ('y', C.c_void_p),
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('KH', C.c_int),
                 ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('relu', C.c_int), ('residual_mode', C.c_int),
-                ('Hr', C.c_int), ('Wr', C.c_int)]
+                ('Hr', C.c_int), ('Wr', C.c_int), ('x2', C.c_void_p), ('Cin2', C.c_int), ('stride2', C.c_int), ('H2', C.c_int),
+                ('W2', C.c_int)]
 
 
 class ConvWeights(C.Structure):
@@ -43,7 +44,7 @@ class ConvWeights(C.Structure):
 
 class ModelWeights(C.Structure):
     _fields_ = [('blocks', C.c_int * 4), ('stem', ConvWeights), ('convs', C.POINTER(ConvWeights)), ('num_convs', C.c_int),
-                ('lateral', ConvWeights * 4), ('fpn_out', ConvWeights * 4), ('init_boxes', C.c_void_p),
+                ('lateral', ConvWeights * 4), ('fpn_out', ConvWeights * 4), ('c3_ds', ConvWeights * 4), ('init_boxes', C.c_void_p),
                 ('init_feats', C.c_void_p), ('num_stages', C.c_int), ('stage_weights', C.POINTER(C.c_void_p)),
                 ('gaze_weights', C.POINTER(C.c_void_p)), ('bbox_stds', C.c_float * 4)]
 

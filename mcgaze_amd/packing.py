@@ -61,7 +61,7 @@ def dyn_permutation(d=256, feat=64):
 class PackedWeights:
     """Device-resident packed weights + the geometry tables the engine needs."""
 
-    def __init__(self, state_dict, depth=50, num_stages=4, dtype=torch.bfloat16, device='cuda:0'):
+    def __init__(self, state_dict, depth=50, num_stages=4, dtype=torch.bfloat16, device='cuda:0', fuse_downsample=True):
         sd = normalize_state_dict(state_dict)
         self.dtype, self.device, self.depth, self.num_stages = dtype, torch.device(device), depth, num_stages
         self.blocks = ARCH[depth]
@@ -74,6 +74,7 @@ class PackedWeights:
         stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
         self.stem = dict(w=mat(stem), bias=vec(b), cin=32, cout=64, k=7, stride=2, pad=3)
         self.convs = []
+        self.c3_ds = []  # per layer: first block's conv3 + downsample as one K-concatenated 1x1 conv
         for li, nb in enumerate(self.blocks):
             for bi in range(nb):
                 p = f'backbone.layer{li + 1}.{bi}'
@@ -82,8 +83,12 @@ class PackedWeights:
                     w, b = fold_bn(sd, f'{p}.{conv}.weight', f'{p}.{bn}')
                     self.convs.append(dict(w=mat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=k, stride=s, pad=pad))
                 if f'{p}.downsample.0.weight' in sd:
+                    w3, b3 = w, b  # conv3 of this block (last of the loop above)
                     w, b = fold_bn(sd, f'{p}.downsample.0.weight', f'{p}.downsample.1')
                     self.convs.append(dict(w=mat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=1, stride=stride, pad=0))
+                    if fuse_downsample:
+                        wcat = torch.cat([ohwi(w3), ohwi(w)], dim=3)  # [Cout,1,1,planes + inplanes]
+                        self.c3_ds.append(dict(w=mat(wcat), bias=vec(b3 + b), cin=wcat.shape[3], cout=wcat.shape[0], k=1, stride=1, pad=0))
         self.lateral, self.fpn_out = [], []
         for i in range(4):
             w = sd[f'neck.lateral_convs.{i}.conv.weight']

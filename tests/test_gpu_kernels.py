@@ -91,6 +91,26 @@ def test_conv2d(eng, dtype, case):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('stride2', [1, 2])
+def test_conv3_plus_downsample_as_one_k_concatenated_conv(eng, dtype, stride2):
+    """relu(conv3(o2) + downsample(x)) (resnet.py:289-298, res_layer.py:51-61) == one 1x1 conv over [o2 | x@stride]."""
+    g = torch.Generator().manual_seed(77 + stride2)
+    N, Ho, Wo, planes, inpl, cout = 3, 9, 7, 128, 256, 512
+    o2 = torch.randn(N, planes, Ho, Wo, generator=g)
+    x = torch.randn(N, inpl, Ho * stride2, Wo * stride2, generator=g)
+    w3 = torch.randn(cout, planes, 1, 1, generator=g) / planes ** 0.5
+    wd = torch.randn(cout, inpl, 1, 1, generator=g) / inpl ** 0.5
+    b = torch.randn(cout, generator=g)
+    q = lambda t: t.to(dtype).float()
+    ref = F.relu(F.conv2d(q(o2), q(w3)) + F.conv2d(q(x), q(wd), stride=stride2) + b[None, :, None, None])
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dtype).to('cuda:0')
+    wcat = torch.cat([w3, wd], dim=1).permute(0, 2, 3, 1).contiguous().to(dtype).to('cuda:0')
+    y = eng.conv2d(nhwc(o2), wcat, b.to('cuda:0'), relu=True, x2=nhwc(x), stride2=stride2)
+    torch.cuda.synchronize()
+    assert scale_err(y.permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_layout_roundtrip(eng, dtype):
     x = torch.randn(3, 37, 5, 9).to('cuda:0')
     y = eng.to_nhwc(x, dtype)
