@@ -142,6 +142,8 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     else if (tile == 3) launch_dma<T, 256, 256, 64, 4, 2, 3>(s, p, groups);
     else if (tile == 4 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 128, 128, 128, 2, 2, 3>(s, p, groups);
     else if (tile == 5 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 128, 128, 4, 2, 3>(s, p, groups);
+    else if (tile == 6) launch_dma<T, 128, 128, 64, 2, 2, 3>(s, p, groups);
+    else if (tile == 8) launch_dma<T, 128, 256, 64, 2, 2, 3>(s, p, groups);
     else launch_dma<T, 128, 128, 64, 2, 2, 4>(s, p, groups);
   } else if (p.Cout <= 64) {
     if (wide) launch_cfg<T, 128, 64, 128, 4, 1>(s, p, groups);

@@ -108,8 +108,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(co
   // ---- residual prefetch for epilogue pass 0 (latency hidden under the K loop)
   const T* __restrict__ R = (const T*)p.res + (long long)g * p.res_g;
   const bool has_res = p.res_mode != MCG_RES_NONE && p.splitk <= 1;
-  uint4 rpre[CH_PER_THREAD];
-  auto fetch_residual = [&](int pass) {
+  uint4 rpre_a[CH_PER_THREAD], rpre_b[CH_PER_THREAD];  // double-buffered: pass p+1's rows are in flight while pass p is stored
+  auto fetch_residual = [&](int pass, uint4 (&rpre)[CH_PER_THREAD]) {
 #pragma unroll
     for (int q = 0; q < CH_PER_THREAD; ++q) {
       const int idx = tid + q * NT;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(co
       }
     }
   };
-  if (EARLY_RES) fetch_residual(0);
+  if (EARLY_RES) fetch_residual(0, rpre_a);
 
   // ---- per-lane DMA source offsets (bytes, loop-invariant) and in-image tap masks
   const int drow = lane / CPR, dcs = lane % CPR;
@@ -258,9 +258,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(co
 
   // ---- epilogue
   float* C = (float*)smem;
-#pragma unroll 1
+  if (!EARLY_RES) fetch_residual(0, rpre_a);
+#pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
-    if (pass > 0 || !EARLY_RES) fetch_residual(pass);
+    uint4 (&rpre)[CH_PER_THREAD] = (pass & 1) ? rpre_b : rpre_a;
+    if (pass + 1 < PASSES) fetch_residual(pass + 1, (pass & 1) ? rpre_a : rpre_b);
     if (wm / WR_PER_PASS == pass) {
       const int wr = wm % WR_PER_PASS;
 #pragma unroll
