@@ -176,10 +176,17 @@ size_t mcg_engine_workspace_bytes(const mcg_engine* e, int num_frames, int H, in
 /* Backbone + FPN only: img NCHW f32 [N,3,H,W] -> P2..P5 NHWC dtype. */
 int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s, const float* img, int num_frames, int H, int W,
                              int chunk_frames, void* const pyramid[4], void* ws, size_t ws_bytes);
-/* Whole path.  img_hw: DEVICE int [num_frames][2] = img_shape (h, w) per frame, or NULL when every
- * frame fills the padded H x W (query boxes scale with img_shape, fixed_embedding_rpn_head.py:80-89).
- * Outputs (device, f32):
+/* Decoder only: 4 x (RoIAlign + GazeSTQIHead + box refinement) + GazeHead over an existing pyramid
+ * (MultiClueGazeROIHead.simple_test, multiclue_gaze_roi_head.py:287-384).  Separate from the trunk so a caller can
+ * overlap the decoder of batch k with the trunk of batch k+1 on a second stream (mcgaze_amd/engine.py: PipelinedRunner).
+ * img_hw: DEVICE int [num_frames][2] = img_shape (h, w) per frame, or NULL when every frame fills the padded H x W
+ * (query boxes scale with img_shape, fixed_embedding_rpn_head.py:80-89).  Outputs (device, f32):
  *   gaze_out [4][N][3] (fused, face, eyes, head), boxes_out [N][3][4], scores_out [N][3] (sigmoid). */
+size_t mcg_trunk_workspace_bytes(const mcg_engine* e, int num_frames, int H, int W, int chunk_frames);
+size_t mcg_decoder_workspace_bytes(const mcg_engine* e, int num_frames);
+int mcg_decoder_forward(mcg_engine* e, mcg_stream s, const void* const pyramid[4], int num_frames, int clip_length, int H, int W,
+                        const int* img_hw, float* gaze_out, float* boxes_out, float* scores_out, void* ws, size_t ws_bytes);
+/* Whole path = mcg_backbone_fpn_forward + mcg_decoder_forward on one stream; ws >= mcg_engine_workspace_bytes. */
 int mcg_clip_forward(mcg_engine* e, mcg_stream s, const float* img, int num_frames, int clip_length, int H, int W,
                      const int* img_hw, int chunk_frames, float* gaze_out, float* boxes_out, float* scores_out,
                      void* ws, size_t ws_bytes);

@@ -439,8 +439,17 @@ extern "C" int mcg_stage_forward(mcg_stream s_, mcg_dtype dt, const void* const 
   }
   // --- FFN (mmcv FFN with add_identity, gaze_stqi_head.py:179-180)
   MCG_TRY(launch_linear(s, dt, w.x3, 256, W[MCG_SW_FFN1_W], f32w[MCG_SW_FFN1_B], nullptr, 0, w.h, 2048, R, 256, 2048, 1));
-  MCG_TRY(launch_linear(s, dt, w.h, 2048, W[MCG_SW_FFN2_W], f32w[MCG_SW_FFN2_B], w.x3, 256, w.t, 256, R, 2048, 256, 0));
-  MCG_TRY(launch_ln(s, dt, ln_simple(w.t, f32w[MCG_SW_FFN_LN_G], f32w[MCG_SW_FFN_LN_B], 0, obj_out, R, 256)));
+  {  // 2048 -> 256 at M = R rows is only a couple of dozen output tiles: split K so the whole chip works on it; the
+     // LayerNorm kernel sums the slabs, adds bias and the residual, and normalises (deterministic, no atomics)
+    int ffn_slabs = 1;
+    MCG_TRY(launch_linear_splitk(s, dt, w.h, 2048, W[MCG_SW_FFN2_W], w.partial, R, 2048, 256, 8, &ffn_slabs));
+    LnParams p;
+    memset(&p, 0, sizeof(p));
+    p.partial = w.partial; p.slabs = ffn_slabs; p.slab_stride = (long long)R * 256; p.bias = f32w[MCG_SW_FFN2_B];
+    p.res = w.x3; p.g2 = f32w[MCG_SW_FFN_LN_G]; p.b2 = f32w[MCG_SW_FFN_LN_B];
+    p.dst = obj_out; p.M = R; p.D = 256; p.src_ld = 256; p.res_ld = 256; p.dst_ld = 256; p.rows_per_group = 1 << 30;
+    MCG_TRY(launch_ln(s, dt, p));
+  }
   // --- towers (gaze_stqi_head.py:185-188)
   MCG_TRY(launch_linear(s, dt, obj_out, 256, W[MCG_SW_CLS_FC_W], nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0));
   MCG_TRY(launch_ln(s, dt, ln_simple(w.c1, f32w[MCG_SW_CLS_LN_G], f32w[MCG_SW_CLS_LN_B], 1, w.clsf, R, 256)));

@@ -156,37 +156,44 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
   return MCG_OK;
 }
 
-struct ClipWs {
-  char* pyr[4];
-  char *roi, *obj_a, *obj_b, *stage_ws, *gaze_ws, *trunk_ws;
+// Decoder scratch for N frames (RoI features, query state, per-stage and gaze-head workspaces).
+struct DecWs {
+  char *roi, *obj_a, *obj_b, *stage_ws, *gaze_ws;
   float *boxes_a, *boxes_b, *cls;
-  size_t stage_bytes, gaze_bytes, trunk_bytes, total;
+  size_t stage_bytes, gaze_bytes, total;
 };
-static ClipWs clip_layout(mcg_dtype dt, int N, int H, int W, int chunk, bool with_decoder, char* base) {
-  const size_t es = esize(dt);
-  ClipWs c;
+static DecWs dec_layout(mcg_dtype dt, int N, char* base) {
+  const size_t es = esize(dt), R = (size_t)N * 3;
+  DecWs c;
   memset(&c, 0, sizeof(c));
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
-  if (chunk <= 0 || chunk > N) chunk = N;
-  c.trunk_bytes = trunk_layout(dt, chunk, H, W, nullptr).total;
-  c.trunk_ws = take(c.trunk_bytes);
-  if (with_decoder) {
-    for (int i = 0; i < 4; ++i) c.pyr[i] = take((size_t)N * ((H / 4) >> i) * ((W / 4) >> i) * 256 * es);
-    const size_t R = (size_t)N * 3;
-    c.roi = take(R * 49 * 256 * es);
-    c.obj_a = take(R * 256 * es); c.obj_b = take(R * 256 * es);
-    c.boxes_a = (float*)take(R * 4 * 4); c.boxes_b = (float*)take(R * 4 * 4); c.cls = (float*)take(R * 4);
-    c.stage_bytes = mcg_stage_workspace_bytes(dt, N); c.stage_ws = take(c.stage_bytes);
-    c.gaze_bytes = mcg_gaze_head_workspace_bytes(dt, N); c.gaze_ws = take(c.gaze_bytes);
-  }
+  c.roi = take(R * 49 * 256 * es);
+  c.obj_a = take(R * 256 * es); c.obj_b = take(R * 256 * es);
+  c.boxes_a = (float*)take(R * 4 * 4); c.boxes_b = (float*)take(R * 4 * 4); c.cls = (float*)take(R * 4);
+  c.stage_bytes = mcg_stage_workspace_bytes(dt, N); c.stage_ws = take(c.stage_bytes);
+  c.gaze_bytes = mcg_gaze_head_workspace_bytes(dt, N); c.gaze_ws = take(c.gaze_bytes);
   c.total = off;
   return c;
 }
+static size_t pyramid_bytes(mcg_dtype dt, int N, int H, int W, int level) {
+  return al256((size_t)N * ((H / 4) >> level) * ((W / 4) >> level) * 256 * esize(dt));
+}
 
+extern "C" size_t mcg_trunk_workspace_bytes(const mcg_engine* e, int N, int H, int W, int chunk) {
+  if (!e || N <= 0) return 0;
+  if (chunk <= 0 || chunk > N) chunk = N;
+  return trunk_layout(e->dt, chunk, H, W, nullptr).total;
+}
+extern "C" size_t mcg_decoder_workspace_bytes(const mcg_engine* e, int N) {
+  if (!e || N <= 0) return 0;
+  return dec_layout(e->dt, N, nullptr).total;
+}
 extern "C" size_t mcg_engine_workspace_bytes(const mcg_engine* e, int N, int H, int W, int chunk) {
   if (!e || N <= 0) return 0;
-  return clip_layout(e->dt, N, H, W, chunk, true, nullptr).total;
+  size_t total = mcg_trunk_workspace_bytes(e, N, H, W, chunk) + mcg_decoder_workspace_bytes(e, N);
+  for (int i = 0; i < 4; ++i) total += pyramid_bytes(e->dt, N, H, W, i);
+  return total;
 }
 
 static int check_shape(int N, int H, int W) {
@@ -206,18 +213,14 @@ extern "C" int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s_, const floa
   return MCG_OK;
 }
 
-extern "C" int mcg_clip_forward(mcg_engine* e, mcg_stream s_, const float* img, int N, int clip_length, int H, int W,
-                                const int* img_hw, int chunk, float* gaze_out, float* boxes_out, float* scores_out,
-                                void* ws, size_t ws_bytes) {
+extern "C" int mcg_decoder_forward(mcg_engine* e, mcg_stream s_, const void* const pyramid[4], int N, int clip_length, int H, int W,
+                                   const int* img_hw, float* gaze_out, float* boxes_out, float* scores_out, void* ws, size_t ws_bytes) {
   hipStream_t s = (hipStream_t)s_;
-  MCG_CHECK_ARG(e && img && gaze_out && boxes_out && scores_out && ws, "mcg_clip_forward: null pointer");
+  MCG_CHECK_ARG(e && pyramid && gaze_out && boxes_out && scores_out && ws, "mcg_decoder_forward: null pointer");
   MCG_TRY(check_shape(N, H, W));
-  MCG_CHECK_ARG(clip_length > 0 && N % clip_length == 0, "mcg_clip_forward: num_frames=%d is not a multiple of clip_length=%d", N, clip_length);
-  if (chunk <= 0 || chunk > N) chunk = N;
-  ClipWs c = clip_layout(e->dt, N, H, W, chunk, true, (char*)ws);
-  if (ws_bytes < c.total) { mcg_set_error("mcg_clip_forward: workspace too small (%zu < %zu)", ws_bytes, c.total); return MCG_ERR_WORKSPACE; }
-  void* pyr[4] = {c.pyr[0], c.pyr[1], c.pyr[2], c.pyr[3]};
-  for (int f0 = 0; f0 < N; f0 += chunk) MCG_TRY(trunk_chunk(e, s, img, f0, (N - f0) < chunk ? (N - f0) : chunk, H, W, pyr, c.trunk_ws));
+  MCG_CHECK_ARG(clip_length > 0 && N % clip_length == 0, "num_frames=%d is not a multiple of clip_length=%d", N, clip_length);
+  DecWs c = dec_layout(e->dt, N, (char*)ws);
+  if (ws_bytes < c.total) { mcg_set_error("mcg_decoder_forward: workspace too small (%zu < %zu)", ws_bytes, c.total); return MCG_ERR_WORKSPACE; }
   MCG_TRY(launch_init_queries(s, e->dt, e->init_boxes, e->init_feats, img_hw, H, W, c.boxes_a, c.obj_a, N));
   int fh[4], fw[4];
   const int strides[4] = {4, 8, 16, 32};
@@ -225,7 +228,7 @@ extern "C" int mcg_clip_forward(mcg_engine* e, mcg_stream s_, const float* img, 
   char* obj_in = c.obj_a; char* obj_out = c.obj_b;
   float* b_in = c.boxes_a; float* b_out = c.boxes_b;
   for (int st = 0; st < e->num_stages; ++st) {
-    MCG_TRY(launch_roi_align(s, e->dt, pyr, fh, fw, strides, 256, b_in, N * 3, 3, c.roi, nullptr));
+    MCG_TRY(launch_roi_align(s, e->dt, pyramid, fh, fw, strides, 256, b_in, N * 3, 3, c.roi, nullptr));
     float* bdst = (st == e->num_stages - 1) ? boxes_out : b_out;
     MCG_TRY(mcg_stage_forward(s, e->dt, &e->stage_w[(size_t)st * MCG_SW_COUNT], c.roi, obj_in, b_in, N, clip_length, obj_out, bdst,
                               c.cls, e->stds, c.stage_ws, c.stage_bytes));
@@ -235,4 +238,21 @@ extern "C" int mcg_clip_forward(mcg_engine* e, mcg_stream s_, const float* img, 
   MCG_TRY(launch_sigmoid(s, c.cls, scores_out, N * 3));
   MCG_TRY(mcg_gaze_head(s, e->dt, e->gaze_w, obj_in, N, gaze_out, c.gaze_ws, c.gaze_bytes));
   return MCG_OK;
+}
+
+extern "C" int mcg_clip_forward(mcg_engine* e, mcg_stream s_, const float* img, int N, int clip_length, int H, int W,
+                                const int* img_hw, int chunk, float* gaze_out, float* boxes_out, float* scores_out,
+                                void* ws, size_t ws_bytes) {
+  MCG_CHECK_ARG(e && img && gaze_out && boxes_out && scores_out && ws, "mcg_clip_forward: null pointer");
+  MCG_TRY(check_shape(N, H, W));
+  MCG_CHECK_ARG(clip_length > 0 && N % clip_length == 0, "mcg_clip_forward: num_frames=%d is not a multiple of clip_length=%d", N, clip_length);
+  const size_t need = mcg_engine_workspace_bytes(e, N, H, W, chunk);
+  if (ws_bytes < need) { mcg_set_error("mcg_clip_forward: workspace too small (%zu < %zu)", ws_bytes, need); return MCG_ERR_WORKSPACE; }
+  char* base = (char*)ws;
+  const size_t trunk_bytes = mcg_trunk_workspace_bytes(e, N, H, W, chunk);
+  void* pyr[4];
+  size_t off = trunk_bytes;
+  for (int i = 0; i < 4; ++i) { pyr[i] = base + off; off += pyramid_bytes(e->dt, N, H, W, i); }
+  MCG_TRY(mcg_backbone_fpn_forward(e, s_, img, N, H, W, chunk, pyr, base, trunk_bytes));
+  return mcg_decoder_forward(e, s_, pyr, N, clip_length, H, W, img_hw, gaze_out, boxes_out, scores_out, base + off, ws_bytes - off);
 }

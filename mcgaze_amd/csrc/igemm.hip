@@ -119,13 +119,14 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   // DMA tile choice (profiles/r01_b_tile_sweep.md): 0 = 128x128 4 waves 4 stages, 1 = 256x128 4 waves,
   // 3 = 256x256 8 waves, 5 = 256x128 8 waves with 128-byte K slices.  MCG_TILE >= 0 overrides (experiments).
   int tile = 0;
-  if (dma && p.Cout > 64 && p.M >= 128 * 256) {
+  if (dma && p.Cout > 64 && ((long long)p.M * p.Cout >= 128ll * 256 * 256)) {
     const int Kdim = p.KH * p.KW * p.Cin;
     if (big_tile >= 0) tile = big_tile;
     else if (p.Cout <= 128) tile = Kdim >= 1024 ? 1 : 0;
     else if (p.M >= 300000) tile = 3;
     else if (p.M >= 80000) tile = p.Cout >= 512 ? 3 : (((p.Cin * ES) % 128 == 0 && !p.x2) ? 5 : 1);
-    else tile = 1;
+    else if (p.M >= 128 * 256) tile = 1;
+    else tile = (p.Cout >= 4096 && p.M >= 1024) ? 3 : 0;  // few rows, very wide N (the 256 -> 32768 dynamic-parameter layer)
   }
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
   ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;

@@ -218,3 +218,51 @@ class HipEngine:
                                           _ptr(out['gaze']), _ptr(out['boxes']), _ptr(out['scores']), _ptr(ws), ws.numel()),
                 'mcg_clip_forward')
         return out
+
+
+class PipelinedRunner:
+    """Two-deep software pipeline over successive batches (throughput serving): the decoder of batch k
+    (4 x [RoIAlign + stage] + gaze head: ~110 short, latency-bound launches) runs on a second HIP stream and
+    overlaps the trunk of batch k+1, whose large contraction kernels leave CUs idle only at their tails.
+    Pyramids are double-buffered; trunks serialise on stream A, decoders on stream B, ordered by events.
+    Every submitted batch is fully processed once ``flush()`` returns control to the caller's stream."""
+
+    def __init__(self, engine, num_frames, H, W, clip_length, chunk_frames=0):
+        self.e, self.N, self.H, self.W, self.T, self.chunk = engine, num_frames, H, W, clip_length, chunk_frames
+        dev, lib, h = engine.device, engine.lib, engine._handle
+        # the decoder's short launches get the high-priority queue so they slot in between the trunk's long kernels
+        self.sa, self.sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)
+        self.pyr = [[torch.empty(num_frames, (H // 4) >> i, (W // 4) >> i, 256, dtype=engine.dtype, device=dev) for i in range(4)] for _ in range(2)]
+        self.tabs = [(C.c_void_p * 4)(*[p.data_ptr() for p in lvl]) for lvl in self.pyr]
+        self.trunk_ws = _ws(lib.mcg_trunk_workspace_bytes(h, num_frames, H, W, chunk_frames), dev)
+        self.dec_ws = _ws(lib.mcg_decoder_workspace_bytes(h, num_frames), dev)
+        self.trunk_done = [torch.cuda.Event() for _ in range(2)]
+        self.dec_done = [torch.cuda.Event() for _ in range(2)]
+        self.used = [False, False]
+        self.k = 0
+
+    def submit(self, img, out, img_hw=None):
+        """Enqueue one batch: img [N,3,H,W] f32 (must stay valid until its trunk ran), out = dict(gaze, boxes, scores)."""
+        e, lib, slot = self.e, self.e.lib, self.k & 1
+        cur = torch.cuda.current_stream(e.device)
+        self.sa.wait_stream(cur)                       # input produced on the caller's stream
+        if self.used[slot]:
+            self.sa.wait_event(self.dec_done[slot])    # the decoder that read this pyramid slot has finished
+        L.check(lib.mcg_backbone_fpn_forward(e._handle, C.c_void_p(self.sa.cuda_stream), _ptr(img), self.N, self.H, self.W, self.chunk,
+                                             self.tabs[slot], _ptr(self.trunk_ws), self.trunk_ws.numel()), 'mcg_backbone_fpn_forward')
+        self.trunk_done[slot].record(self.sa)
+        self.sb.wait_event(self.trunk_done[slot])
+        L.check(lib.mcg_decoder_forward(e._handle, C.c_void_p(self.sb.cuda_stream), self.tabs[slot], self.N, self.T, self.H, self.W,
+                                        _ptr(img_hw), _ptr(out['gaze']), _ptr(out['boxes']), _ptr(out['scores']),
+                                        _ptr(self.dec_ws), self.dec_ws.numel()), 'mcg_decoder_forward')
+        self.dec_done[slot].record(self.sb)
+        self.used[slot] = True
+        self.k += 1
+        return self.dec_done[slot]
+
+    def flush(self):
+        """Make the caller's stream wait for every submitted batch."""
+        cur = torch.cuda.current_stream(self.e.device)
+        for slot in range(2):
+            if self.used[slot]:
+                cur.wait_event(self.dec_done[slot])

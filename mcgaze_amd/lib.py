@@ -26,7 +26,8 @@ SW_COUNT, GW_COUNT = len(STAGE_KEYS), len(GAZE_KEYS)
 EXPORTS = ['mcg_abi_version', 'mcg_last_error', 'mcg_device_info', 'mcg_nchw_to_nhwc', 'mcg_nhwc_to_nchw', 'mcg_conv2d',
            'mcg_stem_workspace_bytes', 'mcg_stem_forward', 'mcg_roi_align', 'mcg_stage_workspace_bytes', 'mcg_stage_forward',
            'mcg_gaze_head_workspace_bytes', 'mcg_gaze_head', 'mcg_engine_create', 'mcg_engine_destroy',
-           'mcg_engine_workspace_bytes', 'mcg_backbone_fpn_forward', 'mcg_clip_forward', 'mcg_profile_start', 'mcg_profile_stop']
+           'mcg_engine_workspace_bytes', 'mcg_trunk_workspace_bytes', 'mcg_decoder_workspace_bytes', 'mcg_backbone_fpn_forward',
+           'mcg_decoder_forward', 'mcg_clip_forward', 'mcg_profile_start', 'mcg_profile_stop']
 
 
 class ConvDesc(C.Structure):
@@ -87,6 +88,11 @@ def load():
     lib.mcg_engine_destroy.restype = None
     lib.mcg_engine_workspace_bytes.restype = sz
     lib.mcg_engine_workspace_bytes.argtypes = [vp, i, i, i, i]
+    lib.mcg_trunk_workspace_bytes.restype = sz
+    lib.mcg_trunk_workspace_bytes.argtypes = [vp, i, i, i, i]
+    lib.mcg_decoder_workspace_bytes.restype = sz
+    lib.mcg_decoder_workspace_bytes.argtypes = [vp, i]
+    lib.mcg_decoder_forward.argtypes = [vp, vp, C.POINTER(vp), i, i, i, i, vp, vp, vp, vp, vp, sz]
     lib.mcg_backbone_fpn_forward.argtypes = [vp, vp, vp, i, i, i, i, C.POINTER(vp), vp, sz]
     lib.mcg_clip_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp, vp, vp, vp, sz]
     lib.mcg_profile_start.argtypes = [i]

@@ -156,3 +156,22 @@ def test_registry_surface_reproduces_reference_outputs(golden_dir):
     g, img, B, T, ishape = load_case(golden_dir, 'clip224')
     res, _ = model(img=[torch.from_numpy(img)], img_metas=[synth.make_img_metas(T)], return_loss=False, rescale=False, format=True)
     assert len(res) == T and len(res[0]) == 3 and res[0][0].shape == (1, 5)
+
+
+def test_pipelined_runner_matches_serial_engine(engines):
+    """The two-stream batch pipeline must produce exactly what the serial single-stream path produces, batch by batch."""
+    from mcgaze_amd.engine import PipelinedRunner
+    T, B = 7, 6
+    e = engines['bf16']
+    batches = [torch.from_numpy(synth.make_clips(100 + i, B, T)).to('cuda:0') for i in range(5)]
+    serial = [{k: v.clone() for k, v in e.forward(x, T).items()} for x in batches]
+    runner = PipelinedRunner(e, B * T, 224, 224, T)
+    outs = [dict(gaze=torch.zeros(4, B * T, 3, device='cuda:0'), boxes=torch.zeros(B * T, 3, 4, device='cuda:0'),
+                 scores=torch.zeros(B * T, 3, device='cuda:0')) for _ in batches]
+    for x, o in zip(batches, outs):
+        runner.submit(x, o)
+    runner.flush()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(serial, outs)):
+        for k in ('gaze', 'boxes', 'scores'):
+            assert torch.equal(a[k], b[k]), (i, k)
