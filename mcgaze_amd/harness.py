@@ -1,0 +1,122 @@
+"""Caller of the hot path: the reference's inference harness logic --
+sliding 7-frame windows with stride 4 over every video, one forward per window, overlap merging, result
+records -- restated from tools/test_gaze360_gaze.py:60-269 so that whole videos can be pushed through the
+engine in large batches (the reference runs one clip per forward).
+
+Semantics kept exactly (pinned by tests/golden/harness_merge.json, produced by running the reference's own
+``main`` on a seeded fake model):
+  * windows (:72-86): ``clip_num = ceil((L-7)/4)+1``; the last window is the LAST 7 frames; a video with
+    L <= 7 frames is one short clip of T = L frames (so T is variable);
+  * merge (:129-206): the first window is taken verbatim; later windows append their new frames and average the
+    overlapping ones ``(old+new)/2`` -- gaze vectors are NOT re-normalised; box coordinates are zeroed where the
+    score is < 0.5 in either prediction (the stored score may itself be an average);
+  * record schema (:210-260): per frame fused gaze, per-clue boxes as [x, y, w, h] or None when zeroed, gazes, scores.
+"""
+import json
+import math
+import os
+
+import torch
+
+CLUES = ('face', 'eyes', 'head')
+
+
+def plan_windows(video_length, clip_len=7, stride=4):
+    """-> list of (start, stop, overlap_with_previous).  tools/test_gaze360_gaze.py:72-86."""
+    L = video_length
+    if L <= clip_len:
+        return [(0, L, 0)]
+    clip_num = math.ceil((L - clip_len) / stride) + 1
+    out = []
+    for i in range(clip_num):
+        if i != clip_num - 1:
+            out.append((i * stride, i * stride + clip_len, clip_len - stride))
+        else:
+            rem = (L - clip_len) % stride
+            out.append((L - clip_len, L, clip_len - rem if rem else clip_len - stride))
+    return out
+
+
+def _zero_low_score_boxes(det, thr):
+    coords, score = det[..., :4], det[..., 4:]
+    return torch.cat([torch.where(score < thr, torch.zeros_like(coords), coords), score], dim=-1)
+
+
+def merge_video(windows, clip_outputs, person_threshold=0.5):
+    """windows from plan_windows; clip_outputs[i] = (det_bboxes [T,3,5], fused [T,3], others [T,3,3]) of window i.
+    Returns per-frame (det_bboxes [L,3,5], fused [L,3], others [L,3,3]).  tools/test_gaze360_gaze.py:129-206."""
+    det, fused, others = None, None, None
+    for i, ((start, stop, overlap), (d, f, o)) in enumerate(zip(windows, clip_outputs)):
+        d = _zero_low_score_boxes(d, person_threshold)
+        if i == 0:
+            det, fused, others = d.clone(), f.clone(), o.clone()
+            continue
+        T = stop - start
+        new = T - overlap
+        # overlapping frames: last `overlap` stored frames vs the first `overlap` frames of this window
+        old_d, cur_d = det[-overlap:], d[:overlap]
+        bad = (old_d[..., 4:] < person_threshold) | (cur_d[..., 4:] < person_threshold)
+        coords = torch.where(bad, torch.zeros_like(old_d[..., :4]), (old_d[..., :4] + cur_d[..., :4]) / 2)
+        det[-overlap:] = torch.cat([coords, (old_d[..., 4:] + cur_d[..., 4:]) / 2], dim=-1)
+        fused[-overlap:] = (fused[-overlap:] + f[:overlap]) / 2
+        others[-overlap:] = (others[-overlap:] + o[:overlap]) / 2
+        det = torch.cat([det, d[-new:]])
+        fused = torch.cat([fused, f[-new:]])
+        others = torch.cat([others, o[-new:]])
+    return det, fused, others
+
+
+def video_record(video_id, det, fused, others):
+    """Result record of one video (tools/test_gaze360_gaze.py:210-260)."""
+    det, fused, others = det.detach().cpu(), fused.detach().cpu(), others.detach().cpu()
+    rec = dict(video_id=video_id, category_id=1, fusion_gazes=[])
+    for c in CLUES:
+        rec[f'{c}_bboxes'], rec[f'{c}_gazes'], rec[f'{c}_score'] = [], [], []
+    for t in range(det.shape[0]):
+        rec['fusion_gazes'].append(fused[t].numpy().tolist())
+        for ci, c in enumerate(CLUES):
+            m = det[t, ci, :4].numpy().tolist()
+            rec[f'{c}_bboxes'].append(None if (m[0] + m[1] + m[2] + m[3]) == 0 else [m[0], m[1], m[2] - m[0], m[3] - m[1]])
+            rec[f'{c}_gazes'].append(others[t, ci].numpy().tolist())
+            rec[f'{c}_score'].append(det[t, ci, 4].item())
+    return rec
+
+
+def result_file_name(config_path, json_path):
+    """``results_<config stem>_<annotation file name>`` (tools/test_gaze360_gaze.py:268; note rstrip('.py') semantics)."""
+    return f'results_{config_path.rstrip(".py").split("/")[-1]}_{json_path.split("/")[-1]}'
+
+
+def run_videos(engine, videos, clip_len=7, stride=4, batch_clips=64, scale_factor=None, person_threshold=0.5):
+    """Push whole videos through the HIP engine.
+
+    videos: list of dict(id=…, frames=Tensor[L,3,H,W] f32 already preprocessed (normalised, padded to /32)).
+    All windows of all videos with the same length T are packed into batches of up to ``batch_clips`` clips and run
+    with the batched semantics (N = B*T frames, clip_length = T); results are merged per video on the device.
+    scale_factor (4 floats) divides the boxes like rescale=True does (multiclue_gaze_roi_head.py:360-363)."""
+    plans = [plan_windows(v['frames'].shape[0], clip_len, stride) for v in videos]
+    jobs = {}  # T -> list of (video index, window index)
+    for vi, plan in enumerate(plans):
+        for wi, (a, b, _) in enumerate(plan):
+            jobs.setdefault(b - a, []).append((vi, wi))
+    outputs = [[None] * len(p) for p in plans]
+    dev = engine.device
+    for T, items in sorted(jobs.items()):
+        for s in range(0, len(items), batch_clips):
+            chunk = items[s:s + batch_clips]
+            x = torch.cat([videos[vi]['frames'][plans[vi][wi][0]:plans[vi][wi][1]] for vi, wi in chunk]).to(dev, torch.float32).contiguous()
+            out = engine.forward(x, T)
+            boxes = out['boxes'] if scale_factor is None else out['boxes'] / torch.as_tensor(scale_factor, device=dev, dtype=torch.float32)
+            det = torch.cat([boxes, out['scores'][..., None]], dim=-1)
+            for bi, (vi, wi) in enumerate(chunk):
+                sl = slice(bi * T, (bi + 1) * T)
+                outputs[vi][wi] = (det[sl].clone(), out['gaze'][0, sl].clone(), out['gaze'][1:, sl].permute(1, 0, 2).clone())
+    return [video_record(v['id'], *merge_video(plans[vi], outputs[vi], person_threshold)) for vi, v in enumerate(videos)]
+
+
+def dump_results(records, config_path, json_path, out_dir='results'):
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, result_file_name(config_path, json_path))
+    with open(path, 'w') as f:
+        json.dump(records, f)
+    return path

@@ -139,3 +139,20 @@ def make_img_metas(num_frames, img_shape=(224, 224, 3), pad_shape=None, scale_fa
     return [dict(img_shape=tuple(img_shape), ori_shape=tuple(img_shape), pad_shape=tuple(pad_shape),
                  scale_factor=np.asarray(scale_factor, dtype=np.float32), flip=False,
                  filename=f'{i:05d}.png') for i in range(num_frames)]
+
+
+def fake_clip_outputs(video_id, frames, call_index):
+    """Seeded stand-in for the model's per-clip outputs, used to pin the windowing / overlap-merge logic
+    (tests/test_harness.py, oracle/dev/make_harness_goldens.py): depends on the video, the frame numbers AND the
+    call index, so the two predictions of an overlapped frame differ.  Returns torch tensors
+    det_bboxes [T,3,5] (scores straddle the 0.5 person threshold), fused gaze [T,3], per-clue gazes [T,3,3]."""
+    import torch
+    T = len(frames)
+    rs = np.random.RandomState((video_id * 7919 + call_index * 104729 + frames[0] * 31 + T) & 0x7FFFFFFF)
+    xy = rs.uniform(5, 120, size=(T, 3, 2))
+    wh = rs.uniform(10, 90, size=(T, 3, 2))
+    score = rs.uniform(0.2, 1.0, size=(T, 3, 1))
+    det = np.concatenate([xy, xy + wh, score], axis=-1).astype(np.float32)
+    g = rs.standard_normal((T, 4, 3)).astype(np.float32)
+    g /= np.linalg.norm(g, axis=-1, keepdims=True)
+    return torch.from_numpy(det), torch.from_numpy(g[:, 0]), torch.from_numpy(g[:, 1:])

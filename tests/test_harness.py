@@ -1,0 +1,97 @@
+"""windowing + overlap merge and the MAE metric against goldens produced by running
+the reference's own tools/test_gaze360_gaze.py::main (with a seeded fake model) and tools/calculate_mae_*.py
+(oracle/dev/make_harness_goldens.py)."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mcgaze_amd import harness, metric, synth
+
+
+@pytest.fixture(scope='module')
+def merge_golden(golden_dir):
+    return json.load(open(os.path.join(golden_dir, 'harness_merge.json')))
+
+
+def test_windows_match_the_reference_harness(merge_golden):
+    calls = merge_golden['calls']
+    for vid, L in enumerate(merge_golden['video_lengths'], start=1):
+        want = [c['frames'] for c in calls if c['video'] == vid]
+        got = [list(range(a, b)) for a, b, _ in harness.plan_windows(L)]
+        assert got == want, (L, got, want)
+    # closed-form facts (tools/test_gaze360_gaze.py:72-86)
+    assert harness.plan_windows(7) == [(0, 7, 0)] and harness.plan_windows(3) == [(0, 3, 0)]
+    assert harness.plan_windows(8) == [(0, 7, 3), (1, 8, 6)]
+    assert harness.plan_windows(15) == [(0, 7, 3), (4, 11, 3), (8, 15, 3)]
+
+
+def test_merge_reproduces_the_reference_results(merge_golden):
+    calls = merge_golden['calls']
+    idx = 0
+    for vid, L in enumerate(merge_golden['video_lengths'], start=1):
+        plan = harness.plan_windows(L)
+        outs = []
+        for (a, b, _) in plan:
+            assert calls[idx]['video'] == vid
+            outs.append(synth.fake_clip_outputs(vid, list(range(a, b)), call_index=idx))
+            idx += 1
+        rec = harness.video_record(vid, *harness.merge_video(plan, outs))
+        want = merge_golden['results'][vid - 1]
+        assert rec['video_id'] == want['video_id'] and rec['category_id'] == 1 and set(rec) == set(want)
+        for k, v in want.items():
+            if k.endswith('_bboxes'):
+                assert [x is None for x in rec[k]] == [x is None for x in v], (vid, k)
+                np.testing.assert_allclose([x for x in rec[k] if x is not None], [x for x in v if x is not None], atol=1e-5)
+            elif isinstance(v, list):
+                np.testing.assert_allclose(np.array(rec[k], dtype=np.float64), np.array(v, dtype=np.float64), atol=1e-6, err_msg=f'{vid} {k}')
+        assert len(rec['fusion_gazes']) == L
+    assert idx == len(calls)
+    assert harness.result_file_name('configs/x/fake_cfg.py', '/tmp/abc/fake_test.json') == merge_golden['result_file_name']
+
+
+def test_metric_matches_the_reference_scripts(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, 'metric_kat.json')))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        metric.gaze_error(g['eval'], g['anno'], 'fusion_gazes')
+        metric.gaze_error(g['eval'], g['anno'], 'face_gazes')
+    assert buf.getvalue() == g['gaze360_printed']
+    anno3 = dict(annotations=[a for a in g['anno']['annotations'] for _ in range(3)])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        metric.gaze_error(g['eval'], anno3, 'fusion_gazes', setting='l2cs')
+    assert buf.getvalue() == g['l2cs_printed']
+    k = g['kat']
+    gt, p = torch.tensor(k['g']), torch.tensor(k['p'])
+    sm = metric.smooth_filter(p.clone())
+    np.testing.assert_allclose(sm.numpy(), np.array(k['smooth']), atol=1e-6)
+    # SURVEY.md section 8(f)-2 [probe] values
+    np.testing.assert_allclose(sm.numpy(), [[.2037, .0967, -.9742], [.2076, .0983, -.9733], [.1428, .0341, -.9892]], atol=1e-4)
+    assert abs(float(metric.compute_angular_error(sm, gt)) - 6.7325) < 1e-3 and abs(float(metric.compute_yaw_angular(gt[0])) - 5.7106) < 1e-3
+    assert abs(float(metric.compute_angular_error(gt, gt))) < 0.05  # pred == gt -> ~0 (acos rounding only)
+    assert abs(float(metric.compute_pitch_angular(gt[0])) - k['pitch0']) < 1e-5
+
+
+@pytest.mark.gpu
+def test_run_videos_equals_window_by_window(golden_dir):
+    """Batched driver == one engine call per window + merge (bitwise), over videos of mixed length incl. L < 7."""
+    from mcgaze_amd.engine import HipEngine
+    e = HipEngine(synth.make_state_dict(0), precision='bf16')
+    lengths = [3, 7, 9, 16]
+    videos = [dict(id=i + 1, frames=torch.from_numpy(synth.make_clips(50 + i, 1, L))) for i, L in enumerate(lengths)]
+    recs = harness.run_videos(e, videos, batch_clips=4, scale_factor=(1.4, 1.4, 1.4, 1.4))
+    for v, rec in zip(videos, recs):
+        plan = harness.plan_windows(v['frames'].shape[0])
+        outs = []
+        for a, b, _ in plan:
+            o = e.forward(v['frames'][a:b].to('cuda:0').contiguous(), b - a)
+            det = torch.cat([o['boxes'] / torch.tensor([1.4] * 4, device='cuda:0'), o['scores'][..., None]], dim=-1)
+            outs.append((det.clone(), o['gaze'][0].clone(), o['gaze'][1:].permute(1, 0, 2).clone()))
+        want = harness.video_record(v['id'], *harness.merge_video(plan, outs))
+        assert rec == want
+        assert len(rec['fusion_gazes']) == v['frames'].shape[0]
