@@ -116,17 +116,18 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0 && (!p.x2 || (p.Cin2 * ES) % 128 == 0);
   MCG_CHECK_ARG((p.Cin * ES) % 64 == 0 && (!p.x2 || (p.Cin2 * ES) % 64 == 0), "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
   MCG_CHECK_ARG(p.Cout % (16 / ES) == 0, "igemm: Cout=%d must be a multiple of %d", p.Cout, 16 / ES);
-  // DMA tile choice (profiles/r01_b_tile_sweep.md): 0 = 128x128 4 waves 4 stages, 1 = 256x128 4 waves,
-  // 3 = 256x256 8 waves, 5 = 256x128 8 waves with 128-byte K slices.  MCG_TILE >= 0 overrides (experiments).
-  int tile = 0;
-  if (dma && p.Cout > 64 && ((long long)p.M * p.Cout >= 128ll * 256 * 256)) {
-    const int Kdim = p.KH * p.KW * p.Cin;
+  // DMA tile choice (profiles/r01_d_tile_sweep.md).  What the sweep says: occupancy beats tile size -- 256x128 with 8 waves
+  // and a 2-stage ring (48 KiB LDS -> 3 workgroups = 24 waves per CU) wins almost everywhere; only the very large 3x3
+  // contraction prefers 256x256, and layers with few rows prefer 128x128 (more workgroups).  MCG_TILE >= 0 overrides.
+  //   0 = 128x128 4w 4 stages   1 = 256x128 4w 3st   3 = 256x256 8w 3st   5 = 256x128 8w 128-byte K slices 3st
+  //   8 = 128x128 4w 2st        9 = 256x128 8w 2st   10 = 128x128 4w 3st
+  int tile = 8;
+  if (dma && p.Cout > 64) {
+    const long long Kdim = (long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
     if (big_tile >= 0) tile = big_tile;
-    else if (p.Cout <= 128) tile = Kdim >= 1024 ? 1 : 0;
-    else if (p.M >= 300000) tile = 3;
-    else if (p.M >= 80000) tile = p.Cout >= 512 ? 3 : (((p.Cin * ES) % 128 == 0 && !p.x2) ? 5 : 1);
-    else if (p.M >= 128 * 256) tile = 1;
-    else tile = (p.Cout >= 4096 && p.M >= 1024) ? 3 : 0;  // few rows, very wide N (the 256 -> 32768 dynamic-parameter layer)
+    else if (p.M >= 1000000 && Kdim >= 2048 && p.Cout >= 256) tile = 3;
+    else if (p.M >= 128 * 256 || (p.Cout >= 4096 && p.M >= 1024)) tile = 9;
+    else tile = 8;
   }
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
   ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
@@ -137,14 +138,19 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     (void)hipEventRecord(rec->a, s);
   }
   if (dma) {
-    if (p.Cout <= 64) launch_dma<T, 128, 64, 64, 4, 1, 4>(s, p, groups);
+    if (p.Cout <= 64) { if (big_tile == 20) launch_dma<T, 128, 64, 64, 4, 1, 2>(s, p, groups); else launch_dma<T, 128, 64, 64, 4, 1, 4>(s, p, groups); }
     else if (tile == 1) launch_dma<T, 256, 128, 64, 2, 2, 3>(s, p, groups);
     else if (tile == 2) launch_dma<T, 256, 128, 64, 4, 2, 3>(s, p, groups);
     else if (tile == 3) launch_dma<T, 256, 256, 64, 4, 2, 3>(s, p, groups);
     else if (tile == 4 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 128, 128, 128, 2, 2, 3>(s, p, groups);
     else if (tile == 5 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 128, 128, 4, 2, 3>(s, p, groups);
-    else if (tile == 6) launch_dma<T, 128, 128, 64, 2, 2, 3>(s, p, groups);
-    else if (tile == 8) launch_dma<T, 128, 256, 64, 2, 2, 3>(s, p, groups);
+    else if (tile == 6 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 2, 2>(s, p, groups);
+    else if (tile == 7 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 128, 128, 4, 2, 2>(s, p, groups);
+    else if (tile == 8) launch_dma<T, 128, 128, 64, 2, 2, 2>(s, p, groups);
+    else if (tile == 9) launch_dma<T, 256, 128, 64, 4, 2, 2>(s, p, groups);
+    else if (tile == 10) launch_dma<T, 128, 128, 64, 2, 2, 3>(s, p, groups);
+    else if (tile == 12) launch_dma<T, 128, 128, 64, 4, 2, 2>(s, p, groups);
+    else if (tile == 13) launch_dma<T, 256, 256, 64, 4, 4, 2>(s, p, groups);
     else launch_dma<T, 128, 128, 64, 2, 2, 4>(s, p, groups);
   } else if (p.Cout <= 64) {
     if (wide) launch_cfg<T, 128, 64, 128, 4, 1>(s, p, groups);

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(co
   constexpr int CH_PER_THREAD = PASS_ROWS * CPRO / NT;   // output chunks per thread per pass
   constexpr bool EARLY_RES = TM * TN * 16 + CH_PER_THREAD * 4 <= 144;  // register budget: prefetch residual before the K loop
   static_assert(A_PIECES >= 1 && B_PIECES >= 1 && A_PIECES * RPP * NW == BM && B_PIECES * RPP * NW == BN, "tile / wave count mismatch");
-  static_assert(STAGES >= 3, "ring needs >= 3 stages");
+  static_assert(STAGES >= 2, "ring needs >= 2 stages");
   static_assert(PIECES_PER_WAVE * (STAGES - 2) <= 63, "vmcnt field");
   static_assert(WTM * BN * 4 <= LDS_BYTES, "epilogue staging does not fit");
   static_assert(PASS_ROWS * CPRO % NT == 0, "epilogue chunk split");

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mcgaze_amd import engine as E
 N, H, W, Cin, Cout, k, stride, pad = [int(v) for v in sys.argv[1:9]]
-iters = int(sys.argv[9]) if len(sys.argv) > 9 else 20
+iters = int(sys.argv[9]) if len(sys.argv) > 9 else 50
 res = int(sys.argv[10]) if len(sys.argv) > 10 else 0
 dt = torch.bfloat16
 x = torch.randn(N, H, W, Cin, device='cuda').to(dt)
@@ -12,7 +12,7 @@ w = (torch.randn(Cout, k, k, Cin, device='cuda') / (Cin * k * k) ** 0.5).to(dt)
 b = torch.randn(Cout, device='cuda')
 Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
 r = torch.randn(N, Ho, Wo, Cout, device='cuda').to(dt) if res else None
-for _ in range(3):
+for _ in range(60):
     y = E.conv2d(x, w, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1 if res else 0)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
