@@ -81,11 +81,11 @@ static void launch_cfg(hipStream_t s, const IgemmParams& p, int groups) {
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, BKB, WM, WN>), grid, dim3(256), 0, s, p);
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int ST>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int ST, int MINW = 2>
 static void launch_dma(hipStream_t s, const IgemmParams& p, int groups) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
   dim3 grid(tiles, p.splitk, groups);
-  hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, BKB, WM, WN, ST>), grid, dim3(64 * WM * WN), 0, s, p);
+  hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, BKB, WM, WN, ST, MINW>), grid, dim3(64 * WM * WN), 0, s, p);
 }
 
 // The DMA kernel addresses both operands through 2 GiB buffer descriptors with 32-bit offsets and keeps the
@@ -125,8 +125,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   if (dma && p.Cout > 64) {
     const long long Kdim = (long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
     if (big_tile >= 0) tile = big_tile;
-    else if (p.M >= 1000000 && Kdim >= 2048 && p.Cout >= 256) tile = 3;
-    else if (p.M >= 128 * 256 || (p.Cout >= 4096 && p.M >= 1024)) tile = 9;
+    else if (p.M >= 80000 || (p.Cout >= 1024 && p.M >= 1024)) tile = 9;
     else tile = 8;
   }
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
@@ -138,7 +137,11 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     (void)hipEventRecord(rec->a, s);
   }
   if (dma) {
-    if (p.Cout <= 64) { if (big_tile == 20) launch_dma<T, 128, 64, 64, 4, 1, 2>(s, p, groups); else launch_dma<T, 128, 64, 64, 4, 1, 4>(s, p, groups); }
+    if (p.Cout <= 64) {  // 256x64 tile, 4 waves, 2 stages; the register-capped variant (4 workgroups/CU) pays for long-K (3x3) layers
+      if (big_tile == 23) launch_dma<T, 128, 64, 64, 4, 1, 4>(s, p, groups);
+      else if ((long long)p.KH * p.KW * p.Cin >= 512) launch_dma<T, 256, 64, 64, 4, 1, 2, 4>(s, p, groups);
+      else launch_dma<T, 256, 64, 64, 4, 1, 2>(s, p, groups);
+    }
     else if (tile == 1) launch_dma<T, 256, 128, 64, 2, 2, 3>(s, p, groups);
     else if (tile == 2) launch_dma<T, 256, 128, 64, 4, 2, 3>(s, p, groups);
     else if (tile == 3) launch_dma<T, 256, 256, 64, 4, 2, 3>(s, p, groups);
@@ -149,8 +152,10 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     else if (tile == 8) launch_dma<T, 128, 128, 64, 2, 2, 2>(s, p, groups);
     else if (tile == 9) launch_dma<T, 256, 128, 64, 4, 2, 2>(s, p, groups);
     else if (tile == 10) launch_dma<T, 128, 128, 64, 2, 2, 3>(s, p, groups);
-    else if (tile == 12) launch_dma<T, 128, 128, 64, 4, 2, 2>(s, p, groups);
-    else if (tile == 13) launch_dma<T, 256, 256, 64, 4, 4, 2>(s, p, groups);
+    else if (tile == 12) launch_dma<T, 128, 128, 64, 2, 2, 2, 4>(s, p, groups);
+    else if (tile == 13) launch_dma<T, 128, 128, 64, 2, 2, 2, 5>(s, p, groups);
+    else if (tile == 14) launch_dma<T, 256, 128, 64, 4, 2, 2, 6>(s, p, groups);
+    else if (tile == 15) launch_dma<T, 256, 128, 64, 4, 2, 2, 5>(s, p, groups);
     else launch_dma<T, 128, 128, 64, 2, 2, 4>(s, p, groups);
   } else if (p.Cout <= 64) {
     if (wide) launch_cfg<T, 128, 64, 128, 4, 1>(s, p, groups);

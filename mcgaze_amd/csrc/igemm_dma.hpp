@@ -57,8 +57,8 @@ __device__ __forceinline__ void lds_dma16(uint32_t voffset, const u32x4& srd, ui
       : "memory");
 }
 
-template <typename T, int BM, int BN, int BKB, int WAVES_M, int WAVES_N, int STAGES>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(const IgemmParams p) {
+template <typename T, int BM, int BN, int BKB, int WAVES_M, int WAVES_N, int STAGES, int MINW = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel(const IgemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
   constexpr int ES = (int)sizeof(T);
   constexpr int EPC = 16 / ES;
@@ -78,7 +78,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_dma_kernel(co
   constexpr int PASS_ROWS = WR_PER_PASS * WTM;
   constexpr int CPRO = BN / EPC;                         // output chunks per row
   constexpr int CH_PER_THREAD = PASS_ROWS * CPRO / NT;   // output chunks per thread per pass
-  constexpr bool EARLY_RES = TM * TN * 16 + CH_PER_THREAD * 4 <= 144;  // register budget: prefetch residual before the K loop
+  // register budget: prefetch the first pass's residual before the K loop only when it does not cost occupancy
+  constexpr bool EARLY_RES = TM * TN * 16 + CH_PER_THREAD * 4 <= 144 && MINW <= 2;
   static_assert(A_PIECES >= 1 && B_PIECES >= 1 && A_PIECES * RPP * NW == BM && B_PIECES * RPP * NW == BN, "tile / wave count mismatch");
   static_assert(STAGES >= 2, "ring needs >= 2 stages");
   static_assert(PIECES_PER_WAVE * (STAGES - 2) <= 63, "vmcnt field");
