@@ -32,7 +32,7 @@ CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,
              3: 'igemm_kernel<float,128,128,128,2,2>', 4: 'igemm_kernel<bf16,128,64,64,4,1>', 5: 'igemm_kernel<bf16,128,64,128,4,1>',
              6: 'igemm_kernel<bf16,128,128,64,2,2>', 7: 'igemm_kernel<bf16,128,128,128,2,2>',
              # LDS-DMA pipelined kernel: <dtype, BM, BN, K-slice bytes, waves M, waves N, stages>
-             15: 'igemm_dma_kernel<bf16,128,64,64,4,1,4>', 16: 'igemm_dma_kernel<bf16,128,128,64,2,2,4>',
+             15: 'igemm_dma_kernel<bf16,256,64,64,4,1,2>', 16: 'igemm_dma_kernel<bf16,128,128,64,2,2,4>',
              17: 'igemm_dma_kernel<bf16,256,128,64,2,2,3>', 18: 'igemm_dma_kernel<bf16,256,128,64,4,2,3>',
              19: 'igemm_dma_kernel<bf16,256,256,64,4,2,3>', 20: 'igemm_dma_kernel<bf16,128,128,128,2,2,3>',
              21: 'igemm_dma_kernel<bf16,256,128,128,4,2,3>', 22: 'igemm_dma_kernel<bf16,256,256,128,4,2,2>',
@@ -169,13 +169,14 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(CFG_NAMES[dom])
+            traffic = (json.load(open(tpath)).get(CFG_NAMES[dom]) or {}).get('hbm_bytes_per_launch')
         roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                     'traffic': traffic, 'kernel': CFG_NAMES[dom], 'launches_per_step': n,
                     'avg_launch_ms': round(t_ms / n, 4), 'algorithmic_gflop_per_launch': round(flops / n / 1e9, 2),
                     'all_contraction_launches': {CFG_NAMES[c]: {'launches': v[2], 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
                                                  for c, v in sorted(by.items())},
-                    'sampled': 'every contraction launch of the first timed step, HIP events on the launch stream'}
+                    'sampled': 'every contraction launch of the first timed step, HIP events on the launch stream',
+                    'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_bench_traffic.sh); bytes per launch'}
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -1,0 +1,34 @@
+#!/bin/bash
+# GPU: HBM traffic (FETCH_SIZE, WRITE_SIZE; one counter per pass, MI355X_MICROARCH.md "HBM" section) per contraction-kernel
+# symbol over bench.py's step; writes gpurun_out/pmc_traffic.json (copy to profiles/pmc_traffic.json).
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 240 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o $C --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel-events none --pipeline 0 > $OUT/$C.log 2>&1
+  echo "$C pass rc=$?"
+done
+cd $R
+python - "$OUT" <<'PY'
+import csv, glob, json, re, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for f in glob.glob(f'{out}/{sub}/**/*counter_collection.csv', recursive=True):
+        for row in csv.DictReader(open(f)):
+            if 'igemm' in row['Kernel_Name']:
+                agg[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
+res = {}
+for k, d in agg.items():
+    m = re.search(r'igemm_dma_kernel<unsigned short, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)', k)
+    name = f'igemm_dma_kernel<bf16,{",".join(m.groups())}>' if m else k
+    fetch = sum(d['FETCH_SIZE']) / max(len(d['FETCH_SIZE']), 1) * 1024 * 2   # KiB units; x2: gfx950 FETCH_SIZE counts 128-B requests as 64 B
+    write = sum(d['WRITE_SIZE']) / max(len(d['WRITE_SIZE']), 1) * 1024
+    e = res.setdefault(name, {'fetch_bytes_per_launch': 0, 'write_bytes_per_launch': 0, 'launches_sampled': 0})
+    e['fetch_bytes_per_launch'] += fetch; e['write_bytes_per_launch'] += write; e['launches_sampled'] += len(d['FETCH_SIZE'])
+for k, e in res.items():
+    e['hbm_bytes_per_launch'] = round(e['fetch_bytes_per_launch'] + e['write_bytes_per_launch'])
+    e['fetch_bytes_per_launch'] = round(e['fetch_bytes_per_launch']); e['write_bytes_per_launch'] = round(e['write_bytes_per_launch'])
+    e['note'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, averaged over the launches of this symbol in bench.py steps; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section); L2-miss traffic, Infinity-Cache hits included'
+json.dump(res, open(f'{out}/../pmc_traffic.json', 'w'), indent=1)
+print(json.dumps(res, indent=1))
+PY
