@@ -125,7 +125,15 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   if (dma && p.Cout > 64) {
     const long long Kdim = (long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
     if (big_tile >= 0) tile = big_tile;
-    else if (p.M >= 80000 || (p.Cout >= 1024 && p.M >= 1024)) tile = 9;
+    else if (p.M >= 80000 || (p.Cout >= 1024 && p.M >= 1024)) {
+      // 256x128 tiles hold 2 workgroups per CU (register-limited), 128x128 tiles 3: when the grid is only a round or
+      // two deep, pick the one whose last round is fuller (wave quantisation; layer3's 14x14 maps are the case in point)
+      auto eff = [&](int bm, int bn, int per_cu) {
+        const double rounds = (double)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) / (256.0 * per_cu);
+        return rounds / (double)(long long)(rounds + 0.999999);
+      };
+      tile = (eff(256, 128, 2) + 0.08 < eff(128, 128, 3)) ? 8 : 9;
+    }
     else tile = 8;
   }
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
