@@ -116,25 +116,17 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0 && (!p.x2 || (p.Cin2 * ES) % 128 == 0);
   MCG_CHECK_ARG((p.Cin * ES) % 64 == 0 && (!p.x2 || (p.Cin2 * ES) % 64 == 0), "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
   MCG_CHECK_ARG(p.Cout % (16 / ES) == 0, "igemm: Cout=%d must be a multiple of %d", p.Cout, 16 / ES);
-  // DMA tile choice (profiles/r01_d_tile_sweep.md).  What the sweep says: occupancy beats tile size -- 256x128 with 8 waves
-  // and a 2-stage ring (48 KiB LDS -> 3 workgroups = 24 waves per CU) wins almost everywhere; only the very large 3x3
-  // contraction prefers 256x256, and layers with few rows prefer 128x128 (more workgroups).  MCG_TILE >= 0 overrides.
-  //   0 = 128x128 4w 4 stages   1 = 256x128 4w 3st   3 = 256x256 8w 3st   5 = 256x128 8w 128-byte K slices 3st
+  // DMA tile choice (profiles/r01_d_tile_sweep.md, r01_f_tile_sweep.md).  What the sweeps say: occupancy beats tile size --
+  // 256x128 with 8 waves and a 2-stage ring (48 KiB LDS, 2 workgroups = 16 waves per CU) wins wherever the grid still has
+  // more than a workgroup per CU; below that 128x128 (twice the workgroups), with a 3-stage ring for the decoder's few-row
+  // linears.  MCG_TILE >= 0 overrides.
+  //   0 = 128x128 4w 4 stages   1 = 256x128 4w 3st   2 = 256x128 8w 3st   3 = 256x256 8w 3st
   //   8 = 128x128 4w 2st        9 = 256x128 8w 2st   10 = 128x128 4w 3st
   int tile = 8;
   if (dma && p.Cout > 64) {
-    const long long Kdim = (long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
+    const long long blocks9 = (long long)((p.M + 255) / 256) * ((p.Cout + 127) / 128);
     if (big_tile >= 0) tile = big_tile;
-    else if (p.M >= 80000 || (p.Cout >= 1024 && p.M >= 1024)) {
-      // 256x128 tiles hold 2 workgroups per CU (register-limited), 128x128 tiles 3: when the grid is only a round or
-      // two deep, pick the one whose last round is fuller (wave quantisation; layer3's 14x14 maps are the case in point)
-      auto eff = [&](int bm, int bn, int per_cu) {
-        const double rounds = (double)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) / (256.0 * per_cu);
-        return rounds / (double)(long long)(rounds + 0.999999);
-      };
-      tile = (eff(256, 128, 2) + 0.08 < eff(128, 128, 3)) ? 8 : 9;
-    }
-    else tile = 8;
+    else tile = blocks9 >= 300 ? 9 : (p.M <= 4096 ? 10 : 8);
   }
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
   ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;

@@ -31,6 +31,7 @@
 // (+ nearest-upsampled FPN top-down term) + ReLU are applied on coalesced 16-byte row chunks.
 #pragma once
 #include "igemm.hpp"
+#include <type_traits>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -47,14 +48,24 @@ __device__ __forceinline__ u32x4 make_srd(const void* base) {
 #define MCG_OOB_OFFSET 0xFFFFFF00u
 #define MCG_DMA_MAX_BYTES 0x7FFFFF00ll  // operands must fit the 2 GiB descriptor window
 
-__device__ __forceinline__ void lds_dma16(uint32_t voffset, const u32x4& srd, uint32_t soffset_uniform, uint32_t lds_dst_uniform) {
+// One wave-wide 1 KiB HBM -> LDS piece: lane l's 16 bytes land at LDS (lds_base_uniform + IMM) + 16 * l.
+template <int IMM>
+__device__ __forceinline__ void lds_dma16(uint32_t voffset, const u32x4& srd, uint32_t soffset_uniform, uint32_t lds_base_uniform) {
   asm volatile(
-      "s_mov_b32 m0, %2\n\t"
+      "s_add_u32 m0, %2, %4\n\t"
       "s_nop 0\n\t"
       "buffer_load_dwordx4 %0, %1, %3 offen lds"
       :
-      : "v"(voffset), "s"(srd), "s"(lds_dst_uniform), "s"(soffset_uniform)
-      : "memory");
+      : "v"(voffset), "s"(srd), "s"(lds_base_uniform), "s"(soffset_uniform), "n"(IMM)
+      : "memory", "scc");
+}
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
 }
 
 template <typename T, int BM, int BN, int BKB, int WAVES_M, int WAVES_N, int STAGES, int MINW = 2>
@@ -132,8 +143,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
 
   // ---- per-lane DMA source offsets (bytes, loop-invariant) and in-image tap masks
   const int drow = lane / CPR, dcs = lane % CPR;
-  uint32_t a_voff[A_PIECES], a_voff2[A_PIECES], a_mask[A_PIECES], b_voff[B_PIECES];
-  const int chk = p.nocheck ? 0 : 1;
+  uint32_t a_voff[A_PIECES], a_mask[A_PIECES], a_eff[A_PIECES], b_voff[B_PIECES];
 #pragma unroll
   for (int i = 0; i < A_PIECES; ++i) {
     const int row = (wave * A_PIECES + i) * RPP + drow;
@@ -143,15 +153,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
     const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
     const long long off = (long long)n * p.xs_n + (long long)hi0 * p.xs_h + (long long)wi0 * p.xs_w + chunk * EPC;
     a_voff[i] = (uint32_t)(off * ES);  // wraps below zero for padded border pixels; exact again (mod 2^32) once a valid tap is added
-    uint32_t mask = 0;
-    if (chk) {
+    uint32_t mask = 0xffffffffu;
+    if (!p.nocheck) {
+      mask = 0;
       for (int kh = 0; kh < p.KH; ++kh)
         for (int kw = 0; kw < p.KW; ++kw)
           if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W) mask |= 1u << (kh * p.KW + kw);
     }
     a_mask[i] = mask;
-    a_voff2[i] = (uint32_t)(((long long)n * p.xs2_n + (long long)(ho * p.stride2) * p.xs2_h + (long long)(wo * p.stride2) * p.xs2_w + chunk * EPC) * ES);
   }
+  // second (K-concatenated, 1x1) source: only needed once, when the K loop crosses into it
+  auto second_source_voff = [&](int i) -> uint32_t {
+    const int row = (wave * A_PIECES + i) * RPP + drow;
+    const int chunk = dcs ^ ((row / RPB) % CPR);
+    const int m = min(m0 + row, p.M - 1);
+    const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    return (uint32_t)(((long long)n * p.xs2_n + (long long)(ho * p.stride2) * p.xs2_h + (long long)(wo * p.stride2) * p.xs2_w + chunk * EPC) * ES);
+  };
   const long long K = (long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
 #pragma unroll
   for (int i = 0; i < B_PIECES; ++i) {
@@ -161,51 +179,67 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
     b_voff[i] = (uint32_t)(((long long)n * K + chunk * EPC) * ES);
   }
 
-  // running state of the NEXT K-tile to issue (all scalar): tap index, channel slice
-  int nk_t = kt_begin;
-  int nk_tap = kt_begin / tiles_per_tap;
-  int nk_c = kt_begin - nk_tap * tiles_per_tap;
-  int nk_kh = nk_tap / p.KW, nk_kw = nk_tap - nk_kh * p.KW;
-  // One DMA piece of the next tile (q < A_PIECES: an A piece, else a W piece).  Issuing a piece costs the issuing wave
-  // ~60-180 cycles (MI355X_MICROARCH: "LDS-DMA piece issue cost"), so in the main loop the pieces are spread between
-  // the MFMAs of the current tile instead of being issued back to back right after the barrier.
-  uint32_t is_tap_bytes = 0, is_tap_bit = 0, is_wk_bytes = 0, is_dst = 0;
-  auto issue_begin = [&](int buf) {
-    is_tap_bytes = (uint32_t)(((long long)nk_kh * p.xs_h + (long long)nk_kw * p.xs_w + nk_c * BK) * ES);
-    is_tap_bit = 1u << nk_tap;
-    is_wk_bytes = (uint32_t)nk_t * BKB;
-    is_dst = lds_base + buf * STAGE;
-  };
-  auto issue_piece = [&](int q) {
-    if (q < A_PIECES) {
-      if (nk_t >= KT1) {  // second source (1x1): pure scalar K offset
-        lds_dma16(a_voff2[q], srd_a2, (uint32_t)(nk_t - KT1) * BKB, is_dst + (wave * A_PIECES + q) * 1024);
-      } else if (chk) {  // padded conv: fold the tap into the per-lane offset (exact mod 2^32), zero-fill out-of-image taps
-        const uint32_t v = (a_mask[q] & is_tap_bit) ? a_voff[q] + is_tap_bytes : MCG_OOB_OFFSET;
-        lds_dma16(v, srd_a, 0u, is_dst + (wave * A_PIECES + q) * 1024);
-      } else {    // 1x1 / pre-padded / linear: the tap is a pure scalar offset
-        lds_dma16(a_voff[q], srd_a, is_tap_bytes, is_dst + (wave * A_PIECES + q) * 1024);
-      }
-    } else {
-      const int i = q - A_PIECES;
-      lds_dma16(b_voff[i < B_PIECES ? i : 0], srd_b, is_wk_bytes, is_dst + A_BYTES + (wave * B_PIECES + i) * 1024);
-    }
-  };
-  auto issue_end = [&]() {
-    if (nk_t + 1 < kt_end) {  // prefetches beyond the last K-tile simply re-read it
-      ++nk_t;
-      if (nk_t < KT1 && ++nk_c == tiles_per_tap) {
-        nk_c = 0;
-        ++nk_tap;
-        if (++nk_kw == p.KW) { nk_kw = 0; ++nk_kh; }
-      }
-    }
-  };
-  auto issue_next = [&](int buf) {
-    issue_begin(buf);
+  // ---- issue stream.  K is walked as a sequence of SEGMENTS: one per filter tap (kh, kw) of the first source
+  // (Cin / BK tiles each), then one for the optional second source.  Everything that depends on the segment -- the
+  // descriptor, the per-lane offsets with the tap folded in and out-of-image taps swapped for the out-of-range offset
+  // -- is recomputed only when a segment ends (rare, uniform branch).  Per K-tile the issue costs PIECES_PER_WAVE x
+  // (s_add m0 / s_nop / buffer_load) plus four scalar updates: SQ counters on the earlier per-tile tap bookkeeping
+  // showed ~60 SALU and a dozen branches per 8 MFMAs, the scalar unit as busy as the matrix pipe.
+  const int n_tiles = kt_end - kt_begin;
+  int sg_kh = 0, sg_kw = 0, sg_left = 0;
+  uint32_t sg_bit = 1u, soff_a = 0, soff_b = (uint32_t)kt_begin * BKB;
+  bool sg_second = false;
+  u32x4 srd_cur = srd_a;
+  auto segment_setup = [&]() {
+    if (!sg_second) {
+      const uint32_t tap_bytes = (uint32_t)(((long long)sg_kh * p.xs_h + (long long)sg_kw * p.xs_w) * ES);
 #pragma unroll
-    for (int q = 0; q < PIECES_PER_WAVE; ++q) issue_piece(q);
-    issue_end();
+      for (int i = 0; i < A_PIECES; ++i) a_eff[i] = (a_mask[i] & sg_bit) ? a_voff[i] + tap_bytes : MCG_OOB_OFFSET;
+    } else {
+      srd_cur = srd_a2;
+#pragma unroll
+      for (int i = 0; i < A_PIECES; ++i) a_eff[i] = second_source_voff(i);
+    }
+  };
+  {
+    int c0;
+    if (kt_begin < KT1) {
+      const int tap = kt_begin / tiles_per_tap;
+      c0 = kt_begin - tap * tiles_per_tap;
+      sg_kh = tap / p.KW;
+      sg_kw = tap - sg_kh * p.KW;
+      sg_bit = 1u << tap;
+      sg_left = tiles_per_tap - c0;
+    } else {
+      c0 = kt_begin - KT1;
+      sg_second = true;
+      sg_left = KT - kt_begin;
+    }
+    soff_a = (uint32_t)c0 * BKB;
+    segment_setup();
+  }
+  auto segment_advance = [&]() {
+    soff_a = 0;
+    if (!sg_second) {
+      sg_bit <<= 1;
+      if (++sg_kw == p.KW) { sg_kw = 0; ++sg_kh; }
+      if (sg_kh == p.KH) { sg_second = true; sg_left = p.x2 ? p.Cin2 / BK : 0x7fffffff; if (!p.x2) return; }
+      else sg_left = tiles_per_tap;
+    } else {
+      sg_left = 0x7fffffff;
+      return;
+    }
+    segment_setup();
+  };
+  const uint32_t dst_a = lds_base + wave * (A_PIECES * 1024), dst_b = lds_base + A_BYTES + wave * (B_PIECES * 1024);
+  // ring slot = compile-time byte offset IMM (main loop) + uniform run-time offset roff (remainder loop)
+  auto issue_tile = [&](auto imm_c, uint32_t roff) {
+    constexpr int IMM = decltype(imm_c)::value;
+    static_for<A_PIECES>([&](auto i) { lds_dma16<IMM + decltype(i)::value * 1024>(a_eff[decltype(i)::value], srd_cur, soff_a, dst_a + roff); });
+    static_for<B_PIECES>([&](auto i) { lds_dma16<IMM + decltype(i)::value * 1024>(b_voff[decltype(i)::value], srd_b, soff_b, dst_b + roff); });
+    soff_a += BKB;
+    soff_b += BKB;
+    if (--sg_left == 0) segment_advance();
   };
 
   f32x16 acc[TM][TN];
@@ -216,43 +250,63 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int fa[TM], fb[TN], ka[TM], kb[TN];
+  // fragment addresses: every 32-row fragment of a wave shares the swizzle key (32 / RPB is a multiple of CPR), so one
+  // VGPR per K-chunk pair and operand; fragment index and ring stage are immediates of the ds_read
+  static_assert((32 / RPB) % CPR == 0, "swizzle key must repeat every 32 rows");
+  const int fkey = ((lane & 31) / RPB) % CPR;
+  const char* fa[CPR / 2];
+  const char* fb[CPR / 2];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int r = wm * WTM + i * 32 + (lane & 31);
-    fa[i] = r * BKB;
-    ka[i] = (r / RPB) % CPR;
+  for (int j2 = 0; j2 < CPR / 2; ++j2) {
+    const int cb = ((2 * j2 + (lane >> 5)) ^ fkey) << 4;
+    fa[j2] = smem + (wm * WTM + (lane & 31)) * BKB + cb;
+    fb[j2] = smem + A_BYTES + (wn * WTN + (lane & 31)) * BKB + cb;
   }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int r = wn * WTN + j * 32 + (lane & 31);
-    fb[j] = A_BYTES + r * BKB;
-    kb[j] = (r / RPB) % CPR;
-  }
-
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s) issue_next(s);
-  int cur = 0, nxt = STAGES - 1;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_PER_WAVE * (STAGES - 2)) : "memory");
-    __builtin_amdgcn_s_barrier();
-    issue_next(nxt);
-    const char* base = smem + cur * STAGE;
+  auto compute_tile = [&](auto imm_c, uint32_t roff) {
+    constexpr int IMM = decltype(imm_c)::value;
 #pragma unroll
     for (int j2 = 0; j2 < CPR / 2; ++j2) {
-      const int ch = 2 * j2 + (lane >> 5);
       uint4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *(const uint4*)(base + fa[i] + ((ch ^ ka[i]) << 4));
+      for (int i = 0; i < TM; ++i) af[i] = *(const uint4*)(fa[j2] + roff + IMM + i * 32 * BKB);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *(const uint4*)(base + fb[j] + ((ch ^ kb[j]) << 4));
+      for (int j = 0; j < TN; ++j) bf[j] = *(const uint4*)(fb[j2] + roff + IMM + j * 32 * BKB);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
     }
-    cur = (cur + 1 == STAGES) ? 0 : cur + 1;
-    nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
+  };
+  typedef std::integral_constant<int, 0> zero_c;
+
+  // tile t lives in ring slot t % STAGES; the slot tile t-1 just released receives tile t + STAGES - 1
+  const int n_pre = min(n_tiles, STAGES - 1);
+  static_for<STAGES - 1>([&](auto s) { if (decltype(s)::value < n_pre) issue_tile(std::integral_constant<int, decltype(s)::value * STAGE>{}, 0u); });
+  const int n_main = n_tiles - n_pre;  // tiles whose step still has a successor to issue
+  int kt = 0;
+  for (; kt + STAGES <= n_main; kt += STAGES)  // steady state, unrolled over the ring so slots are immediates
+    static_for<STAGES>([&](auto s) {
+      constexpr int S = decltype(s)::value;
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES_PER_WAVE * (STAGES - 2)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_tile(std::integral_constant<int, ((S + STAGES - 1) % STAGES) * STAGE>{}, 0u);
+      compute_tile(std::integral_constant<int, S * STAGE>{}, 0u);
+    });
+  // remainder (< STAGES issuing steps) and drain (n_pre steps, nothing left to issue): rolled, run-time slot
+  uint32_t rs = 0, rn = (STAGES - 1) * STAGE;
+#pragma nounroll
+  for (; kt < n_tiles; ++kt) {
+    if (kt < n_main) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES_PER_WAVE * (STAGES - 2)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_tile(zero_c{}, rn);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    compute_tile(zero_c{}, rs);
+    rs = rs + STAGE == STAGES * STAGE ? 0 : rs + STAGE;
+    rn = rn + STAGE == STAGES * STAGE ? 0 : rn + STAGE;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing prefetch pieces must land before LDS is reused
   __syncthreads();
