@@ -34,10 +34,10 @@ CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,
              # LDS-DMA pipelined kernel: <dtype, BM, BN, K-slice bytes, waves M, waves N, stages>
              15: 'igemm_dma_kernel<bf16,256,64,64,4,1,2>', 16: 'igemm_dma_kernel<bf16,128,128,64,2,2,4>',
              17: 'igemm_dma_kernel<bf16,256,128,64,2,2,3>', 18: 'igemm_dma_kernel<bf16,256,128,64,4,2,3>',
-             19: 'igemm_dma_kernel<bf16,256,256,64,4,2,3>', 20: 'igemm_dma_kernel<bf16,128,128,128,2,2,3>',
-             21: 'igemm_dma_kernel<bf16,256,128,128,4,2,3>', 22: 'igemm_dma_kernel<bf16,256,256,128,4,2,2>',
-             23: 'igemm_dma_kernel<bf16,256,128,128,4,2,2>', 24: 'igemm_dma_kernel<bf16,128,128,64,2,2,2>',
-             25: 'igemm_dma_kernel<bf16,256,128,64,4,2,2>', 26: 'igemm_dma_kernel<bf16,128,128,64,2,2,3>'}
+             19: 'igemm_dma_kernel<bf16,256,256,64,4,2,3>', 24: 'igemm_dma_kernel<bf16,128,128,64,2,2,2>',
+             25: 'igemm_dma_kernel<bf16,256,128,64,4,2,2>', 26: 'igemm_dma_kernel<bf16,128,128,64,2,2,3>',
+             27: 'igemm_dma_kernel<bf16,256,256,64,4,4,4>', 28: 'igemm_dma_kernel<bf16,256,256,64,4,4,3>',
+             29: 'igemm_dma_kernel<bf16,256,256,64,4,4,2>', 30: 'igemm_dma_kernel<bf16,256,256,128,4,4,2>'}
 
 def parse():
     ap = argparse.ArgumentParser()

@@ -111,7 +111,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   constexpr int ES = (int)sizeof(T);
   // tuning knobs (experiments): MCG_IGEMM=1 selects the register-staged kernel for bf16 too,
   // MCG_FORCE_NARROW=1 its 64-byte K slices, MCG_TILE=1 the 256x128 DMA tile.
-  static const int use_v1 = env_int("MCG_IGEMM", 0), force_narrow = env_int("MCG_FORCE_NARROW", 0), big_tile = env_int("MCG_TILE", -1);
+  static const int use_v1 = env_int("MCG_IGEMM", 0), force_narrow = env_int("MCG_FORCE_NARROW", 0), big_tile = env_int("MCG_TILE", -1), wide16 = env_int("MCG_WIDE16", 1);
   const bool dma = ES == 2 && !use_v1 && dma_eligible(p, ES);
   const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0 && (!p.x2 || (p.Cin2 * ES) % 128 == 0);
   MCG_CHECK_ARG((p.Cin * ES) % 64 == 0 && (!p.x2 || (p.Cin2 * ES) % 64 == 0), "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
@@ -121,11 +121,13 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   // more than a workgroup per CU; below that 128x128 (twice the workgroups), with a 3-stage ring for the decoder's few-row
   // linears.  MCG_TILE >= 0 overrides.
   //   0 = 128x128 4w 4 stages   1 = 256x128 4w 3st   2 = 256x128 8w 3st   3 = 256x256 8w 3st
-  //   8 = 128x128 4w 2st        9 = 256x128 8w 2st   10 = 128x128 4w 3st
+  //   8 = 128x128 4w 2st        9 = 256x128 8w 2st   10 = 128x128 4w 3st   12 = 256x256 16w 3st (one 1024-thread workgroup per CU)
   int tile = 8;
   if (dma && p.Cout > 64) {
     const long long blocks9 = (long long)((p.M + 255) / 256) * ((p.Cout + 127) / 128);
+    const long long Kdim = (long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
     if (big_tile >= 0) tile = big_tile;
+    else if (wide16 && p.Cout % 256 == 0 && Kdim >= 384 && blocks9 >= 320) tile = 12;  // deep K, full 256-wide N blocks: fewest LDS-DMA bytes per FLOP
     else tile = blocks9 >= 300 ? 9 : (p.M <= 4096 ? 10 : 8);
   }
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
@@ -145,17 +147,13 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     else if (tile == 1) launch_dma<T, 256, 128, 64, 2, 2, 3>(s, p, groups);
     else if (tile == 2) launch_dma<T, 256, 128, 64, 4, 2, 3>(s, p, groups);
     else if (tile == 3) launch_dma<T, 256, 256, 64, 4, 2, 3>(s, p, groups);
-    else if (tile == 4 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 128, 128, 128, 2, 2, 3>(s, p, groups);
-    else if (tile == 5 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 128, 128, 4, 2, 3>(s, p, groups);
-    else if (tile == 6 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 2, 2>(s, p, groups);
-    else if (tile == 7 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 128, 128, 4, 2, 2>(s, p, groups);
     else if (tile == 8) launch_dma<T, 128, 128, 64, 2, 2, 2>(s, p, groups);
     else if (tile == 9) launch_dma<T, 256, 128, 64, 4, 2, 2>(s, p, groups);
     else if (tile == 10) launch_dma<T, 128, 128, 64, 2, 2, 3>(s, p, groups);
-    else if (tile == 12) launch_dma<T, 128, 128, 64, 2, 2, 2, 4>(s, p, groups);
-    else if (tile == 13) launch_dma<T, 128, 128, 64, 2, 2, 2, 5>(s, p, groups);
-    else if (tile == 14) launch_dma<T, 256, 128, 64, 4, 2, 2, 6>(s, p, groups);
-    else if (tile == 15) launch_dma<T, 256, 128, 64, 4, 2, 2, 5>(s, p, groups);
+    else if (tile == 11) launch_dma<T, 256, 256, 64, 4, 4, 4, 4>(s, p, groups);
+    else if (tile == 12) launch_dma<T, 256, 256, 64, 4, 4, 3, 4>(s, p, groups);
+    else if (tile == 13) launch_dma<T, 256, 256, 64, 4, 4, 2, 4>(s, p, groups);
+    else if (tile == 14 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 4, 2, 4>(s, p, groups);
     else launch_dma<T, 128, 128, 64, 2, 2, 4>(s, p, groups);
   } else if (p.Cout <= 64) {
     if (wide) launch_cfg<T, 128, 64, 128, 4, 1>(s, p, groups);
