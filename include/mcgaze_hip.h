@@ -191,6 +191,24 @@ int mcg_clip_forward(mcg_engine* e, mcg_stream s, const float* img, int num_fram
                      const int* img_hw, int chunk_frames, float* gaze_out, float* boxes_out, float* scores_out,
                      void* ws, size_t ws_bytes);
 
+/* ---------------------------------------------------------------- test-time preprocessing
+ * One launch replaces the per-frame CPU transforms the reference's test pipeline applies between image decode and the model
+ * (configs/_base_/datasets/gaze360.py:27-36): CenterCrop (mmdet/datasets/pipelines/transforms.py:1036-1052; the window is
+ * chosen by the caller, who owns the RNG draw of :1126-1130) -> Resize(keep_ratio) (transforms.py:216-242, cv2 INTER_LINEAR on
+ * 8-bit pixels) -> Normalize(to_rgb) (:739-755) -> Pad + batch collate (zeros right/below, :665-683) -> HWC->CHW
+ * (formatting.py:229-231).  frames_dev: DEVICE array of num_frames descriptors; every src points at a decoded uint8 frame in
+ * device memory, 3 interleaved channels in cv2 order (BGR), rows src_pitch bytes apart.  The crop window must lie inside the
+ * frame; (out_h, out_w) is the resized size, <= (pad_h, pad_w).  dst: [num_frames][3][pad_h][pad_w] f32 = the `img` tensor
+ * mcg_clip_forward takes.  mean / stdinv: host arrays, channel order of the OUTPUT (RGB when to_rgb). */
+typedef struct mcg_frame_desc {
+  const void* src;
+  int src_h, src_w, src_pitch;
+  int crop_y, crop_x, crop_h, crop_w;
+  int out_h, out_w;
+} mcg_frame_desc;
+int mcg_preprocess_frames(mcg_stream stream, const mcg_frame_desc* frames_dev, int num_frames, float* dst, int pad_h, int pad_w,
+                          const float mean[3], const float stdinv[3], int to_rgb);
+
 /* ---------------------------------------------------------------- measurement aid (bench.py)
  * While armed, every launch of the implicit-GEMM kernel is bracketed by a hipEvent pair on its
  * launch stream.  mcg_profile_stop synchronises, returns per-launch duration (ms), algorithmic

@@ -87,31 +87,72 @@ def result_file_name(config_path, json_path):
     return f'results_{config_path.rstrip(".py").split("/")[-1]}_{json_path.split("/")[-1]}'
 
 
-def run_videos(engine, videos, clip_len=7, stride=4, batch_clips=64, scale_factor=None, person_threshold=0.5):
-    """Push whole videos through the HIP engine.
-
-    videos: list of dict(id=…, frames=Tensor[L,3,H,W] f32 already preprocessed (normalised, padded to /32)).
-    All windows of all videos with the same length T are packed into batches of up to ``batch_clips`` clips and run
-    with the batched semantics (N = B*T frames, clip_length = T); results are merged per video on the device.
-    scale_factor (4 floats) divides the boxes like rescale=True does (multiclue_gaze_roi_head.py:360-363)."""
-    plans = [plan_windows(v['frames'].shape[0], clip_len, stride) for v in videos]
-    jobs = {}  # T -> list of (video index, window index)
-    for vi, plan in enumerate(plans):
-        for wi, (a, b, _) in enumerate(plan):
-            jobs.setdefault(b - a, []).append((vi, wi))
-    outputs = [[None] * len(p) for p in plans]
+def _run_windows(engine, ids, plans, get_window, batch_clips, person_threshold):
+    """Core of run_videos / run_annotation: windows with the same (T, H, W) are packed into batches of up to ``batch_clips``
+    clips and run with the batched semantics (N = B*T frames, clip_length = T); results are merged per video on the device.
+    get_window(vi, wi) -> (frames [T,3,H,W] f32, img_hw [T,2] int or None, scale [T,4] f32 or None)."""
     dev = engine.device
-    for T, items in sorted(jobs.items()):
+    jobs = {}
+    for vi, plan in enumerate(plans):
+        for wi in range(len(plan)):
+            jobs.setdefault((plan[wi][1] - plan[wi][0], vi, wi), None)
+    windows = {k: get_window(k[1], k[2]) for k in jobs}          # video order, window order: the reference's RNG order
+    groups = {}
+    for (T, vi, wi), (x, hw, sc) in windows.items():
+        groups.setdefault((T, x.shape[-2], x.shape[-1]), []).append((vi, wi))
+    outputs = [[None] * len(p) for p in plans]
+    for (T, H, W), items in sorted(groups.items()):
         for s in range(0, len(items), batch_clips):
             chunk = items[s:s + batch_clips]
-            x = torch.cat([videos[vi]['frames'][plans[vi][wi][0]:plans[vi][wi][1]] for vi, wi in chunk]).to(dev, torch.float32).contiguous()
-            out = engine.forward(x, T)
-            boxes = out['boxes'] if scale_factor is None else out['boxes'] / torch.as_tensor(scale_factor, device=dev, dtype=torch.float32)
+            parts = [windows[(T, vi, wi)] for vi, wi in chunk]
+            x = torch.cat([p[0] for p in parts]).to(dev, torch.float32).contiguous()
+            hw = None if parts[0][1] is None else torch.cat([torch.as_tensor(p[1], dtype=torch.int32) for p in parts]).numpy()
+            out = engine.forward(x, T, img_hw=hw)
+            boxes = out['boxes']
+            if parts[0][2] is not None:   # rescale=True: every frame's boxes by its own scale_factor (multiclue_gaze_roi_head.py:360-363)
+                boxes = boxes / torch.cat([torch.as_tensor(p[2], dtype=torch.float32) for p in parts]).to(dev)[:, None, :]
             det = torch.cat([boxes, out['scores'][..., None]], dim=-1)
             for bi, (vi, wi) in enumerate(chunk):
                 sl = slice(bi * T, (bi + 1) * T)
                 outputs[vi][wi] = (det[sl].clone(), out['gaze'][0, sl].clone(), out['gaze'][1:, sl].permute(1, 0, 2).clone())
-    return [video_record(v['id'], *merge_video(plans[vi], outputs[vi], person_threshold)) for vi, v in enumerate(videos)]
+    return [video_record(ids[vi], *merge_video(plans[vi], outputs[vi], person_threshold)) for vi in range(len(plans))]
+
+
+def run_videos(engine, videos, clip_len=7, stride=4, batch_clips=64, scale_factor=None, person_threshold=0.5):
+    """Push whole videos through the HIP engine.
+
+    videos: list of dict(id=…, frames=Tensor[L,3,H,W] f32 already preprocessed (normalised, padded to /32)).
+    scale_factor (4 floats) divides the boxes like rescale=True does (multiclue_gaze_roi_head.py:360-363)."""
+    plans = [plan_windows(v['frames'].shape[0], clip_len, stride) for v in videos]
+
+    def get_window(vi, wi):
+        a, b, _ = plans[vi][wi]
+        sc = None if scale_factor is None else torch.as_tensor(scale_factor, dtype=torch.float32).expand(b - a, 4)
+        return videos[vi]['frames'][a:b], None, sc
+
+    return _run_windows(engine, [v['id'] for v in videos], plans, get_window, batch_clips, person_threshold)
+
+
+def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_clips=64, person_threshold=0.5, rng=None):
+    """tools/test_gaze360_gaze.py:57-269 from the annotation file down: for every ``anno['videos']`` entry (``id``,
+    ``file_names``) each window's frames are loaded and preprocessed ANEW through ``pipeline`` (a
+    mcgaze_amd.pipeline.DevicePipeline built from cfg.data.test.pipeline) -- like the reference, which re-runs its test
+    pipeline, random crop included, for every window (:88-100) -- then all windows go through the engine in large batches
+    and are merged per video.  Frames of a window are drawn in file-name order (the reference sorts its threads' results by
+    file name, :96); ``rng`` seeds the crop draws (default: the global numpy RNG, as upstream)."""
+    import numpy as np
+    rng = np.random if rng is None else rng
+    videos = anno['videos']
+    plans = [plan_windows(len(v['file_names']), clip_len, stride) for v in videos]
+
+    def get_window(vi, wi):
+        a, b, _ = plans[vi][wi]
+        names = sorted(videos[vi]['file_names'][a:b])
+        img, metas = pipeline(names, device=engine.device, rng=rng, img_prefix=root)
+        hw = [m['img_shape'][:2] for m in metas]
+        return img, hw, np.stack([m['scale_factor'] for m in metas])
+
+    return _run_windows(engine, [v['id'] for v in videos], plans, get_window, batch_clips, person_threshold)
 
 
 def dump_results(records, config_path, json_path, out_dir='results'):

@@ -27,7 +27,7 @@ EXPORTS = ['mcg_abi_version', 'mcg_last_error', 'mcg_device_info', 'mcg_nchw_to_
            'mcg_stem_workspace_bytes', 'mcg_stem_forward', 'mcg_roi_align', 'mcg_stage_workspace_bytes', 'mcg_stage_forward',
            'mcg_gaze_head_workspace_bytes', 'mcg_gaze_head', 'mcg_engine_create', 'mcg_engine_destroy',
            'mcg_engine_workspace_bytes', 'mcg_trunk_workspace_bytes', 'mcg_decoder_workspace_bytes', 'mcg_backbone_fpn_forward',
-           'mcg_decoder_forward', 'mcg_clip_forward', 'mcg_profile_start', 'mcg_profile_stop']
+           'mcg_decoder_forward', 'mcg_clip_forward', 'mcg_preprocess_frames', 'mcg_profile_start', 'mcg_profile_stop']
 
 
 class ConvDesc(C.Structure):
@@ -48,6 +48,11 @@ class ModelWeights(C.Structure):
                 ('lateral', ConvWeights * 4), ('fpn_out', ConvWeights * 4), ('c3_ds', ConvWeights * 4), ('init_boxes', C.c_void_p),
                 ('init_feats', C.c_void_p), ('num_stages', C.c_int), ('stage_weights', C.POINTER(C.c_void_p)),
                 ('gaze_weights', C.POINTER(C.c_void_p)), ('bbox_stds', C.c_float * 4)]
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('src_h', C.c_int), ('src_w', C.c_int), ('src_pitch', C.c_int), ('crop_y', C.c_int),
+                ('crop_x', C.c_int), ('crop_h', C.c_int), ('crop_w', C.c_int), ('out_h', C.c_int), ('out_w', C.c_int)]
 
 
 class McgError(RuntimeError):
@@ -95,6 +100,7 @@ def load():
     lib.mcg_decoder_forward.argtypes = [vp, vp, C.POINTER(vp), i, i, i, i, vp, vp, vp, vp, vp, sz]
     lib.mcg_backbone_fpn_forward.argtypes = [vp, vp, vp, i, i, i, i, C.POINTER(vp), vp, sz]
     lib.mcg_clip_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp, vp, vp, vp, sz]
+    lib.mcg_preprocess_frames.argtypes = [vp, vp, i, vp, i, i, C.POINTER(C.c_float), C.POINTER(C.c_float), i]
     lib.mcg_profile_start.argtypes = [i]
     lib.mcg_profile_stop.argtypes = [C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i), C.POINTER(i), i]
     for name in EXPORTS:

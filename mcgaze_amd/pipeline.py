@@ -1,0 +1,307 @@
+"""Test-time data pipeline behind the reference's config surface.
+
+``cfg.data.test.pipeline`` of the reference (configs/_base_/datasets/gaze360.py:27-36 and the L2CS variant
+configs/multiclue_gaze/multiclue_gaze_r50_l2cs.py:31-39) is a list of transform dicts that mmdet's ``Compose``
+(mmdet/datasets/pipelines/compose.py) runs one frame at a time on the CPU.  Here the same dicts build the same-named classes
+from a ``PIPELINES`` registry, but the classes only carry the validated options and the GEOMETRY of their transform (crop
+window, resized size, padded size, meta keys, and the RNG draws the reference makes, in the reference's order).  The pixel
+work of the whole chain runs as ONE HIP launch per clip batch (``mcg_preprocess_frames``): decoded uint8 BGR frames go to the
+device as they are, and the kernel writes the model's ``img`` tensor.  There is no CPU pixel path: without the library
+``DevicePipeline.__call__`` raises.
+
+    pipe = DevicePipeline(cfg.data.test.pipeline)
+    img, img_metas = pipe(frames, device='cuda:0')            # frames: list of HxWx3 uint8 BGR arrays or file names
+    model(img=[img], img_metas=[img_metas], return_loss=False, rescale=True, clip_length=7)
+
+Randomness: the reference's ``CenterCrop(crop_type='relative_range')`` draws the crop size from the global numpy RNG at TEST
+time too (transforms.py:1126-1130), and ``RandomFlip(flip_ratio=0.0)`` consumes one more uniform
+(np.random.choice, transforms.py:463-497).  ``rng`` (default: the global ``np.random``) is drawn from in that order per frame,
+so a seeded single-threaded run reproduces the reference's windows; ``crop_u=<float>`` pins the draw instead.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .registry import Registry
+
+PIPELINES = Registry('pipeline')
+
+
+class FramePlan:
+    """Geometry of one frame on its way through the chain (what the reference keeps in the ``results`` dict)."""
+
+    def __init__(self, shape, filename=None, ori_filename=None):
+        self.ori_shape = tuple(shape)
+        self.filename, self.ori_filename = filename, ori_filename
+        self.crop = (0, 0, shape[0], shape[1])      # y, x, h, w inside the decoded frame
+        self.img_shape = tuple(shape)                # current (h, w, c)
+        self.pad_shape = None
+        self.scale_factor = None
+        self.flip, self.flip_direction = False, None
+        self.img_norm_cfg = None
+        self.resized = False
+
+
+@PIPELINES.register_module()
+class LoadImageFromFile:
+    """loading.py:36-82.  Decode happens on the host (PIL); the array stays uint8 BGR like cv2.imread's."""
+
+    def __init__(self, to_float32=False, color_type='color', channel_order='bgr', file_client_args=dict(backend='disk')):
+        if to_float32 or color_type != 'color' or channel_order != 'bgr' or file_client_args.get('backend', 'disk') != 'disk':
+            raise NotImplementedError('LoadImageFromFile: only uint8 colour BGR frames from disk feed the device pipeline')
+
+    @staticmethod
+    def load(filename):
+        from PIL import Image
+        with Image.open(filename) as im:
+            rgb = np.asarray(im.convert('RGB'))
+        return np.ascontiguousarray(rgb[..., ::-1])
+
+    def plan(self, p, rng):
+        pass
+
+
+@PIPELINES.register_module()
+class CenterCrop:
+    """transforms.py:953-1160: a CENTRED window whose size follows ``crop_type`` (the random offsets are commented out
+    upstream, :1040-1043); 'relative_range' draws ONE uniform for both sides (:1126-1130)."""
+
+    def __init__(self, crop_size, crop_type='absolute', allow_negative_crop=False, recompute_bbox=False, bbox_clip_border=True, crop_u=None):
+        if crop_type not in ['relative_range', 'relative', 'absolute', 'absolute_range']:
+            raise ValueError(f'Invalid crop_type {crop_type}.')
+        if crop_type in ['absolute', 'absolute_range']:
+            assert crop_size[0] > 0 and crop_size[1] > 0
+            assert isinstance(crop_size[0], int) and isinstance(crop_size[1], int)
+        else:
+            assert 0 < crop_size[0] <= 1 and 0 < crop_size[1] <= 1
+        self.crop_size, self.crop_type, self.crop_u = crop_size, crop_type, crop_u
+
+    def _get_crop_size(self, h, w, rng):
+        if self.crop_type == 'absolute':
+            return min(self.crop_size[0], h), min(self.crop_size[1], w)
+        if self.crop_type == 'absolute_range':
+            assert self.crop_size[0] <= self.crop_size[1]
+            crop_h = rng.randint(min(h, self.crop_size[0]), min(h, self.crop_size[1]) + 1)
+            crop_w = rng.randint(min(w, self.crop_size[0]), min(w, self.crop_size[1]) + 1)
+            return crop_h, crop_w
+        if self.crop_type == 'relative':
+            return int(h * self.crop_size[0] + 0.5), int(w * self.crop_size[1] + 0.5)
+        cs = np.asarray(self.crop_size, dtype=np.float32)
+        u = rng.rand(1) if self.crop_u is None else np.asarray([self.crop_u], dtype=np.float64)
+        crop_h, crop_w = cs + u * (1 - cs)
+        return int(h * crop_h + 0.5), int(w * crop_w + 0.5)
+
+    def plan(self, p, rng):
+        if p.resized:
+            raise NotImplementedError('CenterCrop after Resize is not a chain the device kernel fuses')
+        y, x, h, w = p.crop
+        ch, cw = self._get_crop_size(h, w, rng)
+        assert ch > 0 and cw > 0
+        oy, ox = int(max(h - ch, 0) / 2 + 0.5), int(max(w - cw, 0) / 2 + 0.5)
+        ch, cw = min(ch, h - oy), min(cw, w - ox)
+        p.crop = (y + oy, x + ox, ch, cw)
+        p.img_shape = (ch, cw) + p.img_shape[2:]
+
+
+@PIPELINES.register_module()
+class Resize:
+    """transforms.py:31-330 for the single-scale test-time use: keep_ratio -> mmcv.imrescale's size rule, else exact size;
+    bilinear (cv2.INTER_LINEAR), which is what the kernel implements."""
+
+    def __init__(self, img_scale=None, multiscale_mode='range', ratio_range=None, keep_ratio=True, bbox_clip_border=True, backend='cv2',
+                 override=False, interpolation='bilinear'):
+        if isinstance(img_scale, list):
+            if len(img_scale) != 1:
+                raise NotImplementedError('Resize: multi-scale sampling is a training option')
+            img_scale = img_scale[0]
+        if img_scale is None or ratio_range is not None or backend != 'cv2' or interpolation != 'bilinear':
+            raise NotImplementedError('Resize: only img_scale=(w, h) with the cv2 bilinear backend is supported')
+        assert isinstance(img_scale, tuple) and len(img_scale) == 2
+        self.img_scale, self.keep_ratio = img_scale, keep_ratio
+
+    def plan(self, p, rng):
+        if p.resized:
+            raise NotImplementedError('two Resize transforms in one pipeline')
+        h, w = p.img_shape[:2]
+        if self.keep_ratio:
+            f = min(max(self.img_scale) / max(h, w), min(self.img_scale) / min(h, w))
+            new_w, new_h = int(w * float(f) + 0.5), int(h * float(f) + 0.5)
+        else:
+            new_w, new_h = self.img_scale
+        p.scale_factor = np.array([new_w / w, new_h / h, new_w / w, new_h / h], dtype=np.float32)
+        p.img_shape = (new_h, new_w) + p.img_shape[2:]
+        p.pad_shape = p.img_shape
+        p.resized = True
+
+
+@PIPELINES.register_module()
+class RandomFlip:
+    """transforms.py:333-530.  Only the never-flipping test-time setting is supported; it still consumes the uniform
+    np.random.choice draws in the reference (:485)."""
+
+    def __init__(self, flip_ratio=None, direction='horizontal'):
+        if isinstance(flip_ratio, list) or direction != 'horizontal':
+            raise NotImplementedError('RandomFlip: list ratios / non-horizontal directions are training options')
+        if isinstance(flip_ratio, float):
+            assert 0 <= flip_ratio <= 1
+        elif flip_ratio is not None:
+            raise ValueError('flip_ratios must be None, float, or list of float')
+        if flip_ratio:
+            raise NotImplementedError('RandomFlip: flip_ratio > 0 is a training option; the test pipeline uses 0.0')
+        self.flip_ratio = flip_ratio
+
+    def plan(self, p, rng):
+        if self.flip_ratio is not None:
+            rng.random_sample()
+        p.flip, p.flip_direction = False, None
+
+
+@PIPELINES.register_module()
+class Normalize:
+    """transforms.py:722-760."""
+
+    def __init__(self, mean, std, to_rgb=True):
+        self.mean, self.std, self.to_rgb = np.array(mean, dtype=np.float32), np.array(std, dtype=np.float32), to_rgb
+
+    def plan(self, p, rng):
+        p.img_norm_cfg = dict(mean=self.mean, std=self.std, to_rgb=self.to_rgb)
+
+
+@PIPELINES.register_module()
+class Pad:
+    """transforms.py:623-720: zeros below / right, up to a multiple of size_divisor or a fixed size."""
+
+    def __init__(self, size=None, size_divisor=None, pad_to_square=False, pad_val=dict(img=0, masks=0, seg=255)):
+        if pad_to_square:
+            raise NotImplementedError('Pad: pad_to_square')
+        assert size is not None or size_divisor is not None, 'only one of size and size_divisor should be valid'
+        assert size is None or size_divisor is None
+        v = pad_val.get('img', 0) if isinstance(pad_val, dict) else pad_val
+        if v != 0:
+            raise NotImplementedError('Pad: the device kernel pads with zeros')
+        self.size, self.size_divisor = size, size_divisor
+
+    def plan(self, p, rng):
+        h, w = p.img_shape[:2]
+        if self.size is not None:
+            ph, pw = max(self.size[0], h), max(self.size[1], w)
+        else:
+            d = self.size_divisor
+            ph, pw = int(np.ceil(h / d)) * d, int(np.ceil(w / d)) * d
+        p.pad_shape = (ph, pw) + p.img_shape[2:]
+
+
+@PIPELINES.register_module()
+class DefaultFormatBundle:
+    """formatting.py:175-260: HWC -> CHW tensor; the kernel writes that layout."""
+
+    def __init__(self, img_to_float=True, pad_val=dict(img=0, masks=0, seg=255)):
+        pass
+
+    def plan(self, p, rng):
+        if p.pad_shape is None:
+            p.pad_shape = p.img_shape
+        if p.scale_factor is None:
+            p.scale_factor = 1.0
+
+
+@PIPELINES.register_module()
+class ImageToTensor:
+    def __init__(self, keys):
+        self.keys = keys
+
+    def plan(self, p, rng):
+        pass
+
+
+@PIPELINES.register_module()
+class Collect:
+    """formatting.py:279-352."""
+
+    def __init__(self, keys, meta_keys=('filename', 'ori_filename', 'ori_shape', 'img_shape', 'pad_shape', 'scale_factor', 'flip',
+                                        'flip_direction', 'img_norm_cfg')):
+        if list(keys) != ['img']:
+            raise NotImplementedError(f'Collect: the test pipeline collects only img (got {keys})')
+        self.keys, self.meta_keys = keys, meta_keys
+
+    def plan(self, p, rng):
+        pass
+
+    def meta(self, p):
+        return {k: getattr(p, k) for k in self.meta_keys}
+
+
+class DevicePipeline:
+    """``Compose(cfg.data.test.pipeline)`` (mmdet/datasets/pipelines/compose.py:11-51) whose pixel work is one HIP launch."""
+
+    def __init__(self, transforms):
+        self.transforms = [PIPELINES.build(dict(t)) if isinstance(t, dict) else t for t in transforms]
+        kinds = [type(t).__name__ for t in self.transforms]
+        if not kinds or kinds[0] != 'LoadImageFromFile':
+            raise ValueError('the pipeline must start with LoadImageFromFile')
+        if 'Normalize' not in kinds or not any(k in kinds for k in ('DefaultFormatBundle', 'ImageToTensor')) or kinds[-1] != 'Collect':
+            raise ValueError(f'unsupported test pipeline {kinds}: need ... Normalize ... DefaultFormatBundle, Collect')
+        self.collect = self.transforms[-1]
+        self._scratch = {}
+
+    def plan(self, shape, rng=np.random, filename=None, ori_filename=None):
+        p = FramePlan(shape, filename, ori_filename)
+        for t in self.transforms:
+            t.plan(p, rng)
+        if p.pad_shape is None:
+            p.pad_shape = p.img_shape
+        if p.scale_factor is None:
+            p.scale_factor = 1.0
+        return p
+
+    def __call__(self, frames, device='cuda:0', rng=np.random, img_prefix=None, stream=None):
+        """frames: list of HxWx3 uint8 BGR arrays (cv2 order) or file names.  Returns (img [N,3,Hp,Wp] f32 on `device`,
+        img_metas list of N dicts) -- one clip batch, padded to the largest padded frame like mmcv's collate."""
+        lib = L.load()
+        dev = torch.device(device)
+        if dev.type != 'cuda':
+            raise L.McgError('DevicePipeline runs its pixel work on the GPU (mcg_preprocess_frames); there is no CPU path')
+        arrays, plans = [], []
+        for f in frames:
+            if isinstance(f, str):
+                path = os.path.join(img_prefix, f) if img_prefix is not None else f
+                arr, names = LoadImageFromFile.load(path), (path, f)
+            else:
+                arr, names = np.ascontiguousarray(f), (None, None)
+            if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
+                raise TypeError(f'frames must be HxWx3 uint8 arrays, got {arr.dtype} {arr.shape}')
+            arrays.append(arr)
+            plans.append(self.plan(arr.shape, rng, *names))
+        n = len(arrays)
+        if n == 0:
+            return torch.empty(0, 3, 0, 0, dtype=torch.float32, device=dev), []
+        pad_h, pad_w = max(p.pad_shape[0] for p in plans), max(p.pad_shape[1] for p in plans)
+        offs = np.cumsum([0] + [(a.size + 255) // 256 * 256 for a in arrays])
+        host = torch.empty(int(offs[-1]), dtype=torch.uint8).pin_memory()
+        for a, o in zip(arrays, offs):
+            host[int(o):int(o) + a.size] = torch.from_numpy(a.reshape(-1))
+        raw = host.to(dev, non_blocking=True)
+        desc = (L.FrameDesc * n)()
+        for i, (a, p) in enumerate(zip(arrays, plans)):
+            desc[i] = L.FrameDesc(raw.data_ptr() + int(offs[i]), a.shape[0], a.shape[1], a.shape[1] * 3, *p.crop, p.img_shape[0], p.img_shape[1])
+        desc_dev = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(dev)
+        norm = plans[0].img_norm_cfg
+        mean = (C.c_float * 3)(*[float(v) for v in norm['mean']])
+        stdinv = (C.c_float * 3)(*[float(np.float32(1.0 / np.float64(v))) for v in norm['std']])
+        img = torch.empty(n, 3, pad_h, pad_w, dtype=torch.float32, device=dev)
+        s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        L.check(lib.mcg_preprocess_frames(C.c_void_p(s), C.c_void_p(desc_dev.data_ptr()), n, C.c_void_p(img.data_ptr()), pad_h, pad_w,
+                                          mean, stdinv, int(bool(norm['to_rgb']))), 'mcg_preprocess_frames')
+        self._scratch = dict(raw=raw, desc=desc_dev)     # keep the inputs alive until the stream has consumed them
+        metas = []
+        for p in plans:
+            m = self.collect.meta(p)
+            metas.append(m)
+        return img, metas
+
+
+def build_pipeline(transforms):
+    return DevicePipeline(transforms)

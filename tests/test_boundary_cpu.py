@@ -140,3 +140,34 @@ def test_bn_fold_equals_conv_then_bn():
                                          sd['backbone.layer1.0.bn1.running_mean'], sd['backbone.layer1.0.bn1.running_var'],
                                          sd['backbone.layer1.0.bn1.weight'], sd['backbone.layer1.0.bn1.bias'], False, 0., 1e-5)
     assert torch.allclose(torch.nn.functional.conv2d(x, w, b), ref, atol=1e-5)
+
+
+def test_checkpoint_ingestion_envelope_and_key_rewrite(tmp_path):
+    """the mmcv ``.pth`` envelope (``meta`` + ``state_dict``), the DataParallel ``module.`` prefix
+    stripped (mmdet/apis/inference.py:45), ``meta['CLASSES']`` taken over (:46-53), extra / missing keys tolerated with a
+    warning (mmcv load_checkpoint is non-strict), a bare state_dict accepted, a non-dict rejected."""
+    from mcgaze_amd import init_detector
+    from mcgaze_amd.apis import load_checkpoint
+    ref = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(5).items()}
+    env = dict(meta=dict(CLASSES=('a', 'b', 'c'), mmdet_version='2.x'), state_dict={'module.' + k: v for k, v in ref.items()},
+               optimizer=dict(state={}))
+    env['state_dict']['module.roi_head.some_dead_head.weight'] = torch.zeros(3)      # unexpected key
+    dropped = 'roi_head.bbox_head.0.fc_cls.weight'                                    # dead at inference (SURVEY.md 8(f)-4)
+    del env['state_dict']['module.' + dropped]
+    path = str(tmp_path / 'ckpt.pth')
+    torch.save(env, path)
+    with pytest.warns(UserWarning, match='missing keys'):
+        model = init_detector(OWN_CFG, path, device='cpu')
+    assert model.CLASSES == ('a', 'b', 'c') and model.cfg.clip_length == 7 and not model.training
+    sd = model.state_dict()
+    for k, v in ref.items():
+        if k != dropped:
+            assert torch.equal(sd[k], v), k
+    bare = str(tmp_path / 'bare.pth')
+    torch.save(ref, bare)
+    _, m2 = build(OWN_CFG)
+    load_checkpoint(m2, bare, strict=True)
+    assert torch.equal(m2.state_dict()[dropped], ref[dropped])
+    torch.save([1, 2, 3], bare)
+    with pytest.raises(RuntimeError, match='No state_dict'):
+        load_checkpoint(m2, bare)

@@ -95,3 +95,38 @@ def test_run_videos_equals_window_by_window(golden_dir):
         want = harness.video_record(v['id'], *harness.merge_video(plan, outs))
         assert rec == want
         assert len(rec['fusion_gazes']) == v['frames'].shape[0]
+
+
+@pytest.mark.gpu
+def test_run_annotation_from_files_equals_window_by_window(tmp_path):
+    """Annotation file -> decoded frames -> device preprocessing (random crop per window, seeded) -> batched engine ->
+    merge, against the same thing done one window at a time (tools/test_gaze360_gaze.py:57-269 end to end)."""
+    from PIL import Image
+    from mcgaze_amd import Config
+    from mcgaze_amd.engine import HipEngine
+    from mcgaze_amd.pipeline import DevicePipeline
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pipe = DevicePipeline(Config.fromfile(os.path.join(root, 'configs', 'mcgaze', 'r50_clip7_gaze360.py')).data.test.pipeline)
+    e = HipEngine(synth.make_state_dict(0), precision='bf16')
+    rs = np.random.RandomState(4)
+    anno = dict(videos=[])
+    for vid, (L, shape) in enumerate([(9, (250, 250, 3)), (5, (300, 280, 3)), (12, (250, 250, 3))]):
+        names = []
+        for i in range(L):
+            names.append(f'v{vid}/{i:06d}.png')
+            os.makedirs(str(tmp_path / f'v{vid}'), exist_ok=True)
+            Image.fromarray(rs.randint(0, 256, shape).astype(np.uint8)).save(str(tmp_path / names[-1]))
+        anno['videos'].append(dict(id=vid + 10, file_names=names))
+    recs = harness.run_annotation(e, anno, str(tmp_path), pipe, batch_clips=3, rng=np.random.RandomState(21))
+    rng = np.random.RandomState(21)
+    for v, rec in zip(anno['videos'], recs):
+        plan = harness.plan_windows(len(v['file_names']))
+        outs = []
+        for a, b, _ in plan:
+            img, metas = pipe(v['file_names'][a:b], device='cuda:0', rng=rng, img_prefix=str(tmp_path))
+            o = e.forward(img, b - a, img_hw=[m['img_shape'][:2] for m in metas])
+            sc = torch.as_tensor(np.stack([m['scale_factor'] for m in metas])).to('cuda:0')[:, None, :]
+            det = torch.cat([o['boxes'] / sc, o['scores'][..., None]], dim=-1)
+            outs.append((det.clone(), o['gaze'][0].clone(), o['gaze'][1:].permute(1, 0, 2).clone()))
+        want = harness.video_record(v['id'], *harness.merge_video(plan, outs))
+        assert rec == want and len(rec['fusion_gazes']) == len(v['file_names'])
