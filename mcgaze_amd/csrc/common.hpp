@@ -14,12 +14,15 @@ typedef uint16_t bf16_t;  // storage type of a bf16 element
 #define MCG_WAVE 64
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// f32 -> bf16, round-to-nearest-even: gfx950's v_cvt_pk_bf16_f32 (two values per instruction; a software RNE costs ~6 VALU each
+// and the epilogues convert every output element)
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  const f32x2_hw v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -49,8 +52,7 @@ __device__ __forceinline__ uint4 f32_to_chunk(const float (&v)[4], float*) {
   return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
 }
 __device__ __forceinline__ uint4 f32_to_chunk(const float (&v)[8], bf16_t*) {
-  return make_uint4((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16),
-                    (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16), (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16));
+  return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }
 
 // One 32x32 MFMA "chunk pair" step: each lane holds 16 bytes of A (row lane&31) and 16 bytes of B

@@ -1,6 +1,7 @@
 // Host launchers for the implicit-GEMM kernel + the trunk's memory-bound helpers
 // (stem input packing, 3x3/s2 max-pool, NCHW<->NHWC).
 #include "igemm_dma.hpp"
+#include "stem_fused.hpp"
 
 #include <stdarg.h>
 #include <stdlib.h>
@@ -315,6 +316,11 @@ extern "C" int mcg_stem_forward(mcg_stream s_, mcg_dtype dt, const float* img, c
   if (ws_bytes < mcg_stem_workspace_bytes(dt, N, H, W)) {
     mcg_set_error("mcg_stem_forward: workspace too small (%zu < %zu)", ws_bytes, mcg_stem_workspace_bytes(dt, N, H, W));
     return MCG_ERR_WORKSPACE;
+  }
+  const int fused = env_int("MCG_STEM_FUSED", 1);  // read per call: tests flip it to compare the two paths
+  if (dt == MCG_BF16 && fused) {  // one kernel, no conv-map round trip (stem_fused.hpp); bit-identical to the path below
+    if (launch_stem_fused(s, img, w_stem, bias, y, N, H, W)) { mcg_set_error("stem_fused launch failed"); return MCG_ERR_HIP; }
+    return MCG_OK;
   }
   const size_t es = dt == MCG_BF16 ? 2 : 4;
   const int Hp = H + 6, Wp = W + 8, Hc = H / 2, Wc = W / 2;

@@ -131,6 +131,23 @@ def test_stem(eng, sd, dtype):
     assert scale_err(y.permute(0, 3, 1, 2), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 96), (3, 224, 224), (1, 320, 448), (2, 36, 52)])
+def test_fused_stem_is_bit_identical_to_the_three_kernel_path(eng, sd, shape, monkeypatch):
+    """stem_fused.hpp keeps the unfused path's packing and K order, so not even rounding may differ -- incl. sizes whose
+    pooled map is not a multiple of the 8x8 tile (36x52 -> 9x13)."""
+    from mcgaze_amd.packing import PackedWeights
+    pw = PackedWeights(sd, dtype=torch.bfloat16)
+    n, h, w = shape
+    img = torch.from_numpy(synth.make_clips(7, 1, n, h, w)).to('cuda:0')
+    monkeypatch.setenv('MCG_STEM_FUSED', '0')
+    a = eng.stem(img, pw.stem['w'], pw.stem['bias'], torch.bfloat16).clone()
+    monkeypatch.setenv('MCG_STEM_FUSED', '1')
+    b = eng.stem(img, pw.stem['w'], pw.stem['bias'], torch.bfloat16)
+    torch.cuda.synchronize()
+    assert a.shape == b.shape == (n, h // 4, w // 4, 64)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_roi_align_all_levels(eng, dtype):
     g = torch.Generator().manual_seed(5)
