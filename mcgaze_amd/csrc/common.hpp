@@ -55,6 +55,18 @@ __device__ __forceinline__ uint4 f32_to_chunk(const float (&v)[8], bf16_t*) {
   return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }
 
+// ReLU on a stored 16-byte chunk.  bf16: sign-magnitude patterns order like signed 16-bit integers, so a packed signed max with 0
+// clears exactly the negative values (v_pk_max_i16, 4 instructions per 8 elements).
+typedef short s16x8_hw __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint4 relu_chunk(const uint4& c, float*) {
+  return make_uint4(__float_as_uint(fmaxf(__uint_as_float(c.x), 0.f)), __float_as_uint(fmaxf(__uint_as_float(c.y), 0.f)),
+                    __float_as_uint(fmaxf(__uint_as_float(c.z), 0.f)), __float_as_uint(fmaxf(__uint_as_float(c.w), 0.f)));
+}
+__device__ __forceinline__ uint4 relu_chunk(const uint4& c, bf16_t*) {
+  const s16x8_hw z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_bit_cast(uint4, __builtin_elementwise_max(__builtin_bit_cast(s16x8_hw, c), z));
+}
+
 // One 32x32 MFMA "chunk pair" step: each lane holds 16 bytes of A (row lane&31) and 16 bytes of B
 // (column lane&31) taken from K-chunk 2j + (lane>>5).  bf16: one v_mfma_f32_32x32x16_bf16.
 // f32: four v_mfma_f32_32x32x2_f32 (exact f32 fma chain); the K order inside the pair is

@@ -144,16 +144,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   // ---- per-lane DMA source offsets (bytes, loop-invariant) and in-image tap masks
   const int drow = lane / CPR, dcs = lane % CPR;
   uint32_t a_voff[A_PIECES], a_mask[A_PIECES], a_eff[A_PIECES], b_voff[B_PIECES];
+  const bool a_linear = p.pad == 0 && p.nocheck &&
+                        (HoWo == 1 || (p.stride == 1 && p.xs_h == (long long)p.Wo * p.xs_w && p.xs_n == (long long)p.Ho * p.xs_h));
+  const long long a_slope = HoWo == 1 ? p.xs_n : p.xs_w;
 #pragma unroll
   for (int i = 0; i < A_PIECES; ++i) {
     const int row = (wave * A_PIECES + i) * RPP + drow;
     const int chunk = dcs ^ ((row / RPB) % CPR);
     const int m = min(m0 + row, p.M - 1);  // rows beyond M re-read the last row; their outputs are never stored
+    uint32_t mask = 0xffffffffu;
+    if (a_linear) {  // dense unpadded stride-1 input (every 1x1 conv and linear): the offset is affine in m, no divisions
+      a_voff[i] = (uint32_t)(((long long)m * a_slope + chunk * EPC) * ES);
+      a_mask[i] = mask;
+      continue;
+    }
     const int n = m / HoWo, rem = m - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
     const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
     const long long off = (long long)n * p.xs_n + (long long)hi0 * p.xs_h + (long long)wi0 * p.xs_w + chunk * EPC;
     a_voff[i] = (uint32_t)(off * ES);  // wraps below zero for padded border pixels; exact again (mod 2^32) once a valid tap is added
-    uint32_t mask = 0xffffffffu;
     if (!p.nocheck) {
       mask = 0;
       for (int kh = 0; kh < p.KH; ++kh)
@@ -314,6 +322,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   // ---- epilogue
   float* C = (float*)smem;
   if (!EARLY_RES) fetch_residual(0, rpre_a);
+  // every chunk a thread stores lies in the same 16-byte column group (NT is a multiple of the chunks per row): its bias
+  // values and column pointer are fetched once
+  static_assert(NT % CPRO == 0, "epilogue column ownership");
+  const int cth = (tid % CPRO) * EPC, rth = tid / CPRO;
+  const bool col_ok = n0 + cth < p.Cout;
+  T* yrow = (T*)p.y + (long long)g * p.y_g + n0 + cth + (long long)(m0 + rth) * p.y_row_stride;  // + uniform row steps per store
+  float bv[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) bv[e] = 0.f;
+  if (p.bias && col_ok && p.splitk <= 1) {
+    const float* Bv = p.bias + (long long)g * p.bias_g + n0 + cth;
+#pragma unroll
+    for (int e = 0; e < EPC; e += 4) {
+      const float4 t = *(const float4*)(Bv + e);
+      bv[e] = t.x; bv[e + 1] = t.y; bv[e + 2] = t.z; bv[e + 3] = t.w;
+    }
+  }
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     uint4 (&rpre)[CH_PER_THREAD] = (pass & 1) ? rpre_b : rpre_a;
@@ -339,26 +364,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
         if (m < p.M && n < p.Cout) *(float4*)(P + (long long)m * p.Cout + n) = *(const float4*)(C + r * BN + c);
       }
     } else {
-      T* Y = (T*)p.y + (long long)g * p.y_g;
-      const float* Bv = p.bias ? p.bias + (long long)g * p.bias_g : nullptr;
 #pragma unroll
       for (int q = 0; q < CH_PER_THREAD; ++q) {
-        const int idx = tid + q * NT;
-        const int r = idx / CPRO, c = (idx - r * CPRO) * EPC;
-        const int m = mbase + r, n = n0 + c;
-        if (m >= p.M || n >= p.Cout) continue;
+        const int r = rth + q * (NT / CPRO);
+        if (mbase + r >= p.M || !col_ok) continue;
         float v[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; e += 4) {
-          const float4 t = *(const float4*)(C + r * BN + c + e);
-          v[e] = t.x; v[e + 1] = t.y; v[e + 2] = t.z; v[e + 3] = t.w;
-        }
-        if (Bv) {
-#pragma unroll
-          for (int e = 0; e < EPC; e += 4) {
-            const float4 t = *(const float4*)(Bv + n + e);
-            v[e] += t.x; v[e + 1] += t.y; v[e + 2] += t.z; v[e + 3] += t.w;
-          }
+          const float4 t = *(const float4*)(C + r * BN + cth + e);
+          v[e] = t.x + bv[e]; v[e + 1] = t.y + bv[e + 1]; v[e + 2] = t.z + bv[e + 2]; v[e + 3] = t.w + bv[e + 3];
         }
         if (has_res) {
           float rv[EPC];
@@ -366,11 +380,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
 #pragma unroll
           for (int e = 0; e < EPC; ++e) v[e] += rv[e];
         }
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        *(uint4*)(Y + (long long)m * p.y_row_stride + n) = f32_to_chunk(v, (T*)nullptr);
+        uint4 o = f32_to_chunk(v, (T*)nullptr);
+        if (p.relu) o = relu_chunk(o, (T*)nullptr);
+        *(uint4*)(yrow + (long long)(pass * PASS_ROWS + q * (NT / CPRO)) * p.y_row_stride) = o;
       }
     }
     if (pass + 1 < PASSES) __syncthreads();
