@@ -112,7 +112,8 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   constexpr int ES = (int)sizeof(T);
   // tuning knobs (experiments): MCG_IGEMM=1 selects the register-staged kernel for bf16 too,
   // MCG_FORCE_NARROW=1 its 64-byte K slices, MCG_TILE=1 the 256x128 DMA tile.
-  static const int use_v1 = env_int("MCG_IGEMM", 0), force_narrow = env_int("MCG_FORCE_NARROW", 0), big_tile = env_int("MCG_TILE", -1), wide16 = env_int("MCG_WIDE16", 1);
+  static const int use_v1 = env_int("MCG_IGEMM", 0), force_narrow = env_int("MCG_FORCE_NARROW", 0), wide16 = env_int("MCG_WIDE16", 1);
+  const int big_tile = env_int("MCG_TILE", -1);  // read per call: tests and tools/tile_sweep.sh switch tiles inside one process
   const bool dma = ES == 2 && !use_v1 && dma_eligible(p, ES);
   const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0 && (!p.x2 || (p.Cin2 * ES) % 128 == 0);
   MCG_CHECK_ARG((p.Cin * ES) % 64 == 0 && (!p.x2 || (p.Cin2 * ES) % 64 == 0), "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
@@ -123,13 +124,14 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   // linears.  MCG_TILE >= 0 overrides.
   //   0 = 128x128 4w 4 stages   1 = 256x128 4w 3st   2 = 256x128 8w 3st   3 = 256x256 8w 3st
   //   8 = 128x128 4w 2st        9 = 256x128 8w 2st   10 = 128x128 4w 3st   12 = 256x256 16w 3st (one 1024-thread workgroup per CU)
+  //   11 = 128x128 8w 2st      15 = 128x128 8w 3st
   int tile = 8;
   if (dma && p.Cout > 64) {
     const long long blocks9 = (long long)((p.M + 255) / 256) * ((p.Cout + 127) / 128);
     const long long Kdim = (long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
     if (big_tile >= 0) tile = big_tile;
     else if (wide16 && p.Cout % 256 == 0 && Kdim >= 384 && blocks9 >= 320) tile = 12;  // deep K, full 256-wide N blocks: fewest LDS-DMA bytes per FLOP
-    else tile = blocks9 >= 300 ? 9 : (p.M <= 4096 ? 10 : 8);
+    else tile = blocks9 >= 300 ? 9 : (p.M <= 4096 ? 11 : 15);  // few rows: 128x128 tiles with 8 waves (32x64 wave tiles, ~85 VGPRs)
   }
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
   ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
@@ -151,7 +153,8 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     else if (tile == 8) launch_dma<T, 128, 128, 64, 2, 2, 2>(s, p, groups);
     else if (tile == 9) launch_dma<T, 256, 128, 64, 4, 2, 2>(s, p, groups);
     else if (tile == 10) launch_dma<T, 128, 128, 64, 2, 2, 3>(s, p, groups);
-    else if (tile == 11) launch_dma<T, 256, 256, 64, 4, 4, 4, 4>(s, p, groups);
+    else if (tile == 11) launch_dma<T, 128, 128, 64, 4, 2, 2>(s, p, groups);
+    else if (tile == 15) launch_dma<T, 128, 128, 64, 4, 2, 3>(s, p, groups);
     else if (tile == 12) launch_dma<T, 256, 256, 64, 4, 4, 3, 4>(s, p, groups);
     else if (tile == 13) launch_dma<T, 256, 256, 64, 4, 4, 2, 4>(s, p, groups);
     else if (tile == 14 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 4, 2, 4>(s, p, groups);

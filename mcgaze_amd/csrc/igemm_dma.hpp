@@ -84,7 +84,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   constexpr int LDS_BYTES = STAGES * STAGE;
   // epilogue passes: as many wave-rows (WTM output rows each) per pass as fit the ring's footprint
   constexpr int WR_FIT = LDS_BYTES / (WTM * BN * 4);
-  constexpr int WR_PER_PASS = WR_FIT >= WAVES_M ? WAVES_M : (WR_FIT >= 1 ? WR_FIT : 1);
+  // ... rounded down to a divisor of WAVES_M: a last pass with fewer wave-rows than the others would store stale staging rows
+  constexpr int WR_PER_PASS = WR_FIT >= WAVES_M ? WAVES_M : (WR_FIT >= 4 && WAVES_M % 4 == 0 ? 4 : (WR_FIT >= 2 && WAVES_M % 2 == 0 ? 2 : 1));
   constexpr int PASSES = (WAVES_M + WR_PER_PASS - 1) / WR_PER_PASS;
   constexpr int PASS_ROWS = WR_PER_PASS * WTM;
   constexpr int CPRO = BN / EPC;                         // output chunks per row
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   static_assert(PIECES_PER_WAVE * (STAGES - 2) <= 63, "vmcnt field");
   static_assert(WTM * BN * 4 <= LDS_BYTES, "epilogue staging does not fit");
   static_assert(PASS_ROWS * CPRO % NT == 0, "epilogue chunk split");
+  static_assert(WAVES_M % WR_PER_PASS == 0, "epilogue passes must tile the wave-rows");
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;

@@ -131,6 +131,26 @@ def test_stem(eng, sd, dtype):
     assert scale_err(y.permute(0, 3, 1, 2), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize('shape', [(21, 14, 14, 256, 256, 3, 1, 1), (3, 28, 28, 128, 512, 1, 1, 0), (2, 30, 22, 64, 256, 3, 2, 1)])
+def test_every_dma_tile_is_bit_identical(eng, shape, monkeypatch):
+    """All tile shapes of igemm_dma_kernel walk K in the same order, so their outputs must agree bit for bit -- which also
+    catches tiling bugs a tolerance hides (a ragged last epilogue pass once wrote stale rows into the next tile)."""
+    n, h, w, cin, cout, k, stride, pad = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).to('cuda:0')
+    wt = (torch.randn(cout, k, k, cin, generator=g) / (cin * k * k) ** 0.5).to(torch.bfloat16).to('cuda:0')
+    b = torch.randn(cout, generator=g).to('cuda:0')
+    ho = (h + 2 * pad - k) // stride + 1
+    r = torch.randn(n, ho, (w + 2 * pad - k) // stride + 1, cout, generator=g).to(torch.bfloat16).to('cuda:0')
+    outs = {}
+    for tile in (9, 0, 1, 2, 3, 8, 10, 11, 12, 13, 15):
+        monkeypatch.setenv('MCG_TILE', str(tile))
+        outs[tile] = eng.conv2d(x, wt, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1).clone()
+    torch.cuda.synchronize()
+    for tile, y in outs.items():
+        assert torch.equal(y.view(torch.int16), outs[9].view(torch.int16)), tile
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 96), (3, 224, 224), (1, 320, 448), (2, 36, 52)])
 def test_fused_stem_is_bit_identical_to_the_three_kernel_path(eng, sd, shape, monkeypatch):
     """stem_fused.hpp keeps the unfused path's packing and K order, so not even rounding may differ -- incl. sizes whose
