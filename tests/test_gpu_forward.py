@@ -175,3 +175,22 @@ def test_pipelined_runner_matches_serial_engine(engines):
     for i, (a, b) in enumerate(zip(serial, outs)):
         for k in ('gaze', 'boxes', 'scores'):
             assert torch.equal(a[k], b[k]), (i, k)
+
+
+@pytest.mark.parametrize('B,T,H,W', [(1, 33, 64, 96), (3, 1, 96, 64), (1, 2, 448, 448)])
+def test_fp32_engine_matches_oracle_on_unusual_shapes(engines, B, T, H, W):
+    """Shapes the reference supports but the goldens do not cover: a long clip (the demo feeds up to 101 frames,
+    SURVEY.md section 8(b)), single-frame clips, and the L2CS input size 448x448 -- fp32 engine vs the oracle at north_star's
+    tolerance (the oracle itself is pinned to the reference by tests/test_oracle.py)."""
+    sd = synth.make_state_dict(0)
+    img = synth.make_clips(100 + T, B, T, H, W)
+    metas = synth.make_img_metas(B * T, (H, W, 3))
+    want_det, want_gaze = orc.forward(sd, img, metas, T)
+    out = engines['fp32'].forward(torch.from_numpy(img).to('cuda:0'), T)
+    torch.cuda.synchronize()
+    for i, k in enumerate(KEYS):
+        d = (orc.yaw_pitch(out['gaze'][i].cpu()) - orc.yaw_pitch(want_gaze[k])).abs().max().item()
+        assert d < F32_TOL, (k, d)
+    np.testing.assert_allclose(out['boxes'].cpu().numpy(), want_det[..., :4].numpy(), atol=5e-2, rtol=1e-4)
+    bf = engines['bf16'].forward(torch.from_numpy(img).to('cuda:0'), T)
+    assert torch.isfinite(bf['gaze']).all() and (orc.yaw_pitch(bf['gaze'][0].cpu()) - orc.yaw_pitch(want_gaze['gaze_score'])).abs().max().item() < BF16_TOL
