@@ -89,15 +89,31 @@ template <> struct Mma<float> {
 // C/D element (reg r of lane l) of a 32x32 MFMA tile: col = l & 31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
 __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// Wave-wide reductions on the DPP path (VALU-speed lane permutes; the __shfl_xor butterfly goes through ds_bpermute, an LDS round
+// trip per step -- one LayerNorm row cost ~1 us of pure latency, and the decoder runs thousands of them).  Rows of 16 lanes reduce
+// with quad_perm / row_half_mirror / row_mirror, rows combine with row_bcast15 / row_bcast31, lane 63 holds the result and is
+// read back as a scalar.  Fixed order -> deterministic.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_mov(float v, float fill) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xB1>(v, 0.f);        // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v, 0.f);        // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v, 0.f);       // row_half_mirror
+  v += dpp_mov<0x140>(v, 0.f);       // row_mirror: every lane holds its row's sum
+  v += dpp_mov<0x142, 0xA>(v, 0.f);  // row_bcast15 into rows 1, 3
+  v += dpp_mov<0x143, 0xC>(v, 0.f);  // row_bcast31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1>(v, v));
+  v = fmaxf(v, dpp_mov<0x4E>(v, v));
+  v = fmaxf(v, dpp_mov<0x141>(v, v));
+  v = fmaxf(v, dpp_mov<0x140>(v, v));
+  v = fmaxf(v, dpp_mov<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_mov<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): give each XCD a contiguous run of

@@ -2,6 +2,7 @@
 // the DynamicConv instance-interaction core, per-clue box/score heads with delta2bbox, the
 // gaze head tail, and query initialisation.  GEMM-shaped work goes through igemm.hpp.
 #include "igemm.hpp"
+#include "chain.hpp"
 
 #include <string.h>
 
@@ -412,13 +413,24 @@ extern "C" int mcg_stage_forward(mcg_stream s_, mcg_dtype dt, const void* const 
   // --- spatial then temporal self-attention with SHARED weights and LayerNorm (gaze_stqi_head.py:148-166)
   const void* xin = obj_in;
   char* xout[2] = {w.x1, w.x2};
+  const char* env_chain0 = getenv("MCG_CHAIN");
+  const bool chain_attn = bf && !(env_chain0 && env_chain0[0] == '0');
   for (int pass = 0; pass < 2; ++pass) {
     MCG_TRY(launch_linear(s, dt, xin, 256, W[MCG_SW_IN_PROJ_W], f32w[MCG_SW_IN_PROJ_B], nullptr, 0, w.qkv, 768, R, 256, 768, 0));
     if (bf) launch_attn<bf16_t>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
     else launch_attn<float>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
     MCG_CHECK_LAUNCH("attn_core");
-    MCG_TRY(launch_linear(s, dt, w.att, 256, W[MCG_SW_OUT_PROJ_W], f32w[MCG_SW_OUT_PROJ_B], xin, 256, w.t, 256, R, 256, 256, 0));
-    MCG_TRY(launch_ln(s, dt, ln_simple(w.t, f32w[MCG_SW_ATTN_LN_G], f32w[MCG_SW_ATTN_LN_B], 0, xout[pass], R, 256)));
+    if (chain_attn) {  // out_proj + residual + LayerNorm as one launch
+      ChainParams cp;
+      memset(&cp, 0, sizeof(cp));
+      cp.x = w.att; cp.M = R; cp.steps = 1;
+      cp.st[0].W = W[MCG_SW_OUT_PROJ_WF]; cp.st[0].bias = f32w[MCG_SW_OUT_PROJ_B]; cp.st[0].res = xin;
+      cp.st[0].g = f32w[MCG_SW_ATTN_LN_G]; cp.st[0].b = f32w[MCG_SW_ATTN_LN_B]; cp.st[0].dst = xout[pass]; cp.st[0].from_input = 1;
+      if (launch_mlp_chain(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
+    } else {
+      MCG_TRY(launch_linear(s, dt, w.att, 256, W[MCG_SW_OUT_PROJ_W], f32w[MCG_SW_OUT_PROJ_B], xin, 256, w.t, 256, R, 256, 256, 0));
+      MCG_TRY(launch_ln(s, dt, ln_simple(w.t, f32w[MCG_SW_ATTN_LN_G], f32w[MCG_SW_ATTN_LN_B], 0, xout[pass], R, 256)));
+    }
     xin = xout[pass];
   }
   // --- DynamicConv (transformer.py:1116-1164)
@@ -451,14 +463,32 @@ extern "C" int mcg_stage_forward(mcg_stream s_, mcg_dtype dt, const void* const 
     MCG_TRY(launch_ln(s, dt, p));
   }
   // --- towers (gaze_stqi_head.py:185-188)
-  MCG_TRY(launch_linear(s, dt, obj_out, 256, W[MCG_SW_CLS_FC_W], nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0));
-  MCG_TRY(launch_ln(s, dt, ln_simple(w.c1, f32w[MCG_SW_CLS_LN_G], f32w[MCG_SW_CLS_LN_B], 1, w.clsf, R, 256)));
   const void* rin = obj_out;
-  char* rbuf[3] = {w.r1, w.r2, w.r1};
-  for (int j = 0; j < 3; ++j) {
-    MCG_TRY(launch_linear(s, dt, rin, 256, (const char*)W[MCG_SW_REG_FC_W] + (size_t)j * 65536 * es, nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0));
-    MCG_TRY(launch_ln(s, dt, ln_simple(w.c1, f32w[MCG_SW_REG_LN_G] + j * 256, f32w[MCG_SW_REG_LN_B] + j * 256, 1, rbuf[j], R, 256)));
-    rin = rbuf[j];
+  const char* env_chain = getenv("MCG_CHAIN");  // read per call: tests compare the fused chain with the launch sequence below
+  const bool chain = bf && !(env_chain && env_chain[0] == '0');
+  if (chain) {  // cls tower + 3-layer reg tower: eight launches as one (chain.hpp), bit-identical
+    ChainParams cp;
+    memset(&cp, 0, sizeof(cp));
+    cp.x = obj_out; cp.M = R; cp.steps = 4;
+    cp.st[0].W = W[MCG_SW_CLS_FC_WF]; cp.st[0].g = f32w[MCG_SW_CLS_LN_G]; cp.st[0].b = f32w[MCG_SW_CLS_LN_B]; cp.st[0].dst = w.clsf;
+    cp.st[0].from_input = 1; cp.st[0].relu = 1;
+    for (int j = 0; j < 3; ++j) {
+      ChainStep& st = cp.st[1 + j];
+      st.W = (const char*)W[MCG_SW_REG_FC_WF] + (size_t)j * 65536 * es;
+      st.g = f32w[MCG_SW_REG_LN_G] + j * 256; st.b = f32w[MCG_SW_REG_LN_B] + j * 256;
+      st.from_input = j == 0; st.relu = 1; st.dst = j == 2 ? w.r1 : nullptr;
+    }
+    if (launch_mlp_chain(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
+    rin = w.r1;
+  } else {
+    MCG_TRY(launch_linear(s, dt, obj_out, 256, W[MCG_SW_CLS_FC_W], nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0));
+    MCG_TRY(launch_ln(s, dt, ln_simple(w.c1, f32w[MCG_SW_CLS_LN_G], f32w[MCG_SW_CLS_LN_B], 1, w.clsf, R, 256)));
+    char* rbuf[3] = {w.r1, w.r2, w.r1};
+    for (int j = 0; j < 3; ++j) {
+      MCG_TRY(launch_linear(s, dt, rin, 256, (const char*)W[MCG_SW_REG_FC_W] + (size_t)j * 65536 * es, nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0));
+      MCG_TRY(launch_ln(s, dt, ln_simple(w.c1, f32w[MCG_SW_REG_LN_G] + j * 256, f32w[MCG_SW_REG_LN_B] + j * 256, 1, rbuf[j], R, 256)));
+      rin = rbuf[j];
+    }
   }
   const float max_ratio = 4.135166556742356f;  // |log(16/1000)|, delta_xywh_bbox_coder.py:236
   if (bf) hipLaunchKernelGGL(heads_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, (const bf16_t*)w.clsf, (const bf16_t*)rin, f32w[MCG_SW_HEAD_CLS_W], f32w[MCG_SW_HEAD_CLS_B], f32w[MCG_SW_HEAD_REG_W], f32w[MCG_SW_HEAD_REG_B], boxes_in, boxes_out, cls_out, R, stds[0], stds[1], stds[2], stds[3], max_ratio);

@@ -48,6 +48,17 @@ def ohwi(w):
     return w.permute(0, 2, 3, 1).contiguous()
 
 
+def frag_major(w):
+    """[..., 256 out, 256 in] -> MFMA-fragment-major [..., t=8][ks=16][lane=64][e=8] with
+    WF[t][ks][lane][e] = W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e] (include/mcgaze_hip.h, MCG_SW_*_WF)."""
+    lead = w.shape[:-2]
+    assert w.shape[-2:] == (256, 256)
+    v = w.reshape(*lead, 8, 32, 16, 2, 8)                      # t, n, ks, half, e
+    n = len(lead)
+    v = v.permute(*range(n), n, n + 2, n + 3, n + 1, n + 4)    # t, ks, half, n, e  -> lane = 32 half + n
+    return v.contiguous().reshape(*lead, 256, 256)
+
+
 def dyn_permutation(d=256, feat=64):
     """Row permutation of dynamic_layer: new row n*d+k <- old row k*feat+n (param_in^T, [feat][d]);
     new row d*feat + n*feat+k <- old row d*feat + k*d+n (param_out^T, [d][feat]); transformer.py:1134-1137."""
@@ -123,6 +134,8 @@ class PackedWeights:
                 HEAD_CLS_B=vec(torch.cat([sd[p + f'.{c}_fc_cls.bias'] for c in CLUES])),
                 HEAD_REG_W=vec(torch.stack([sd[p + f'.{c}_fc_reg.weight'] for c in CLUES])),
                 HEAD_REG_B=vec(torch.stack([sd[p + f'.{c}_fc_reg.bias'] for c in CLUES])))
+            for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W'):   # fragment-major copies for the fused chain kernel (chain.hpp)
+                st[k + 'F'] = frag_major(st[k])
             assert st['HEAD_CLS_W'].shape == (3, 256), 'use_sigmoid=True heads expected (gaze_stqi_head.py:72-75)'
             self.stages.append(st)
         # only the LAST stage's gaze head runs at inference (multiclue_gaze_roi_head.py:367,378)

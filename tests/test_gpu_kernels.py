@@ -212,6 +212,27 @@ def test_decoder_stage(eng, sd, dtype, B, T):
         assert scale_err(boxes_o, boxes_r) < tol, 'boxes'
 
 
+@pytest.mark.parametrize('B,T', [(1, 7), (5, 3), (11, 1)])
+def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T, monkeypatch):
+    """chain.hpp (towers and attention out-projection + LayerNorm as single launches) keeps the K order, the bf16 rounding points
+    and the LayerNorm reduction order of the launch sequence it replaces -- incl. row counts that are not a multiple of its 32-row
+    block."""
+    from mcgaze_amd.packing import PackedWeights
+    pw = PackedWeights(sd, dtype=torch.bfloat16)
+    N = B * T
+    g = torch.Generator().manual_seed(300 + N)
+    roi = (torch.randn(N * 3, 49, 256, generator=g) * 3).to(torch.bfloat16).to('cuda:0')
+    obj = torch.randn(N, 3, 256, generator=g).to(torch.bfloat16).to('cuda:0')
+    boxes = (torch.tensor([[20., 30., 200., 210.], [60., 50., 160., 150.], [90., 60., 130., 100.]])[None].repeat(N, 1, 1) + torch.randn(N, 3, 4, generator=g)).to('cuda:0')
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('MCG_CHAIN', mode)
+        outs[mode] = [t.clone() for t in eng.stage_forward(pw.stages[1], roi, obj, boxes, T)]
+    torch.cuda.synchronize()
+    for a, b, name in zip(outs['0'], outs['1'], ('obj', 'boxes', 'cls')):
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), name
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_gaze_head(eng, sd, dtype):
     from mcgaze_amd.packing import PackedWeights
