@@ -135,7 +135,11 @@ def main():
     drain()
     torch.cuda.synchronize(dev)
     launches = 0
+    user_streams = os.environ.get('MCG_TRUNK_STREAMS')
     if a.kernel_events == 'first':  # count contraction-kernel launches per step (untimed), then arm for the first timed step
+        # The sampled step runs its trunk on ONE stream: with two frame ranges in flight (the default, engine.hip) a launch's
+        # wall time includes the other range's kernels and says nothing about the kernel itself.
+        os.environ['MCG_TRUNK_STREAMS'] = '1'
         cnt = C.c_int()
         L.check(lib.mcg_profile_start(4096), 'mcg_profile_start')
         eng.forward(img, T, chunk_frames=a.chunk_frames, out=outs[0])
@@ -146,8 +150,13 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         step()
+        if i == 0 and a.kernel_events == 'first':  # sampling done: back to the configured number of concurrent frame ranges
+            if user_streams is None:
+                os.environ.pop('MCG_TRUNK_STREAMS', None)
+            else:
+                os.environ['MCG_TRUNK_STREAMS'] = user_streams
     drain()  # the last batch's decoder finishes inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
@@ -175,7 +184,7 @@ def main():
                     'avg_launch_ms': round(t_ms / n, 4), 'algorithmic_gflop_per_launch': round(flops / n / 1e9, 2),
                     'all_contraction_launches': {CFG_NAMES[c]: {'launches': v[2], 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
                                                  for c, v in sorted(by.items())},
-                    'sampled': 'every contraction launch of the first timed step, HIP events on the launch stream',
+                    'sampled': "every contraction launch of the first timed step, HIP events on the launch stream; that step's trunk runs on one stream (MCG_TRUNK_STREAMS=1) so a launch's duration is its own -- the other steps run two frame ranges on concurrent streams",
                     'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_bench_traffic.sh); bytes per launch'}
 
     if dist is not None:
@@ -193,7 +202,8 @@ def main():
                                    f'{B} clips/GPU x {T} frames x 3x{a.size}x{a.size}, {B * world} clips/step',
                        'clips_per_gpu': B, 'clip_length': T, 'global_clips': B * world, 'chunk_frames': a.chunk_frames,
                        'parallelism': f'dp{world} (clips sharded by rank, one fused all_gather of results per step)' if world > 1 else 'single GPU',
-                       'batch_pipeline': 'decoder(step k) overlaps trunk(step k+1) on a second HIP stream; all K batches complete inside the timed region' if a.pipeline else 'none (serial)'},
+                       'batch_pipeline': 'decoder(step k) overlaps trunk(step k+1) on a second HIP stream; all K batches complete inside the timed region' if a.pipeline else 'none (serial)',
+                       'trunk_streams': int(os.environ.get('MCG_TRUNK_STREAMS', '2'))},
             'model_tflops': round(value * FLOPS_PER_CLIP / 1e12, 1),
             'frac_of_bf16_mfma_peak': round(value * FLOPS_PER_CLIP / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             'roofline': roofline,
