@@ -1,10 +1,10 @@
 #!/bin/bash
 # GPU: HBM traffic (FETCH_SIZE, WRITE_SIZE; one counter per pass, MI355X_MICROARCH.md "HBM" section) per contraction-kernel
-# symbol over bench.py's step; writes gpurun_out/pmc_traffic.json (copy to profiles/pmc_traffic.json).
+# symbol over one single-stream step of bench.py (the launches its roofline samples); writes gpurun_out/pmc_traffic.json (copy to profiles/pmc_traffic.json).
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 240 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o $C --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel-events none --pipeline 0 > $OUT/$C.log 2>&1
+  MCG_TRUNK_STREAMS=1 timeout 240 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o $C --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel-events none --pipeline 0 > $OUT/$C.log 2>&1
   echo "$C pass rc=$?"
 done
 cd $R
