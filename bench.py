@@ -87,9 +87,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('MCG_BENCH_FORCE_DIST') == '1':   # the env switch exercises the exchange path on a single GPU
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        # collective kernels on the high-priority queue pool, next to the decoder and exchange streams and away from the trunk's
+        # (streams that share a hardware queue execute in submission order, event waits included -- engine.hip)
+        os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from mcgaze_amd import lib as L
@@ -109,21 +113,33 @@ def main():
     eng.forward(img, T, chunk_frames=a.chunk_frames, out=outs[0])
     state = {'k': 0}
 
+    # The result exchange runs on its own stream, ordered only after the decoder that produced the slot: on the caller's stream
+    # it would sit between successive submits and serialise batch k+1's trunk behind batch k's decoder (the pipeline's whole point).
+    comm = torch.cuda.Stream(device=dev, priority=-1) if dist is not None else None
+    gathered = [None, None]
+
     def step():
         slot = state['k'] & 1
         state['k'] += 1
+        cur = torch.cuda.current_stream(dev)
+        if comm is not None and gathered[slot] is not None:
+            cur.wait_event(gathered[slot])   # the slot's previous exchange has read the buffer the engine is about to rewrite
         if runner is not None:
             done = runner.submit(img, outs[slot])
-            if world > 1:
-                torch.cuda.current_stream(dev).wait_event(done)
         else:
             eng.forward(img, T, chunk_frames=a.chunk_frames, out=outs[slot])
-        if world > 1:
-            gathers[slot].all_gather()
+            done = cur.record_event()
+        if comm is not None:
+            comm.wait_event(done)
+            with torch.cuda.stream(comm):
+                gathers[slot].all_gather()
+            gathered[slot] = comm.record_event()
 
     def drain():
         if runner is not None:
             runner.flush()
+        if comm is not None:
+            torch.cuda.current_stream(dev).wait_stream(comm)
 
     def barrier():
         if dist is not None:

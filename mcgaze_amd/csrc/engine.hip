@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <vector>
 
 int launch_roi_align(hipStream_t s, mcg_dtype dt, const void* const feats[4], const int feat_h[4], const int feat_w[4],
@@ -33,10 +34,40 @@ struct mcg_engine {
   std::vector<const void*> stage_w;  // [num_stages][MCG_SW_COUNT]
   const void* gaze_w[MCG_GW_COUNT];
   float stds[4];
-  static constexpr int kMaxSplit = 4;
-  hipStream_t side[kMaxSplit - 1] = {};
-  hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {};
+  static constexpr int kMaxSplit = 4, kCandidates = 8;
+  hipStream_t cand[kCandidates] = {};            // side-stream candidates (engine-owned)
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {}, ev_probe[3] = {};
+  std::map<hipStream_t, std::vector<int>> side_of;  // caller stream -> candidates on OTHER hardware queues (probed once)
 };
+// ~150 us of wall clock (s_memrealtime ticks at 100 MHz), one wave
+__global__ void probe_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+// Candidates that run CONCURRENTLY with caller stream s, best effort and cached per stream.  A first-call cost of about a
+// millisecond and a host wait (set-up, not the hot path).
+static const std::vector<int>& side_streams_for(mcg_engine* e, hipStream_t s) {
+  auto it = e->side_of.find(s);
+  if (it != e->side_of.end()) return it->second;
+  std::vector<int> good, rest;
+  const long long ticks = 15000;
+  for (int c = 0; c < mcg_engine::kCandidates; ++c) {
+    bool concurrent = false;
+    if (hipEventRecord(e->ev_probe[0], s) == hipSuccess) {
+      hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, s, ticks);
+      hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, e->cand[c], ticks);
+      float ms = 0.f;
+      if (hipEventRecord(e->ev_probe[1], s) == hipSuccess && hipEventRecord(e->ev_probe[2], e->cand[c]) == hipSuccess &&
+          hipEventSynchronize(e->ev_probe[1]) == hipSuccess && hipEventSynchronize(e->ev_probe[2]) == hipSuccess &&
+          hipEventElapsedTime(&ms, e->ev_probe[0], e->ev_probe[2]) == hipSuccess)
+        concurrent = ms < 0.15f * 1.6f;  // both spins inside ~1.6 spin lengths: they overlapped
+    }
+    (concurrent ? good : rest).push_back(c);
+  }
+  (void)hipGetLastError();
+  good.insert(good.end(), rest.begin(), rest.end());  // fall back to serialised candidates rather than fail
+  return e->side_of.emplace(s, good).first->second;
+}
 static const int kMinFramesPerRange = 56;  // below this a range's kernels no longer fill the chip on their own
 static int trunk_ranges(int frames) {
   const char* v = getenv("MCG_TRUNK_STREAMS");  // read per call (bench.py samples per-launch durations with 1)
@@ -75,9 +106,15 @@ extern "C" int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, m
   memcpy(e->gaze_w, w->gaze_weights, sizeof(e->gaze_w));
   memcpy(e->stds, w->bbox_stds, sizeof(e->stds));
   bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; i < mcg_engine::kMaxSplit - 1; ++i)
-    ok = ok && hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  // Side-stream candidates.  The ROCm runtime packs the streams of a priority level onto at most GPU_MAX_HW_QUEUES (4) hardware
+  // queues, and two streams on one hardware queue execute in submission order INCLUDING each other's event waits: a frame range
+  // on a stream that shares a queue with the caller's runs after it, not beside it (10.1 ms instead of 8.75 for 448 frames,
+  // tools/stream_pairs.py).  Which streams share a queue depends on every stream the process has created (a process group's, a
+  // framework's pool), so the engine keeps several candidates and, the first time it sees a caller stream, measures which of them
+  // actually run concurrently with it (side_streams_for).
+  for (int i = 0; i < mcg_engine::kCandidates; ++i) ok = ok && hipStreamCreateWithFlags(&e->cand[i], hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < mcg_engine::kMaxSplit - 1; ++i) ok = ok && hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < 3; ++i) ok = ok && hipEventCreate(&e->ev_probe[i]) == hipSuccess;
   if (!ok) {
     mcg_engine_destroy(e);
     mcg_set_error("mcg_engine_create: could not create the side streams / events");
@@ -95,10 +132,12 @@ extern "C" int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, m
 extern "C" void mcg_engine_destroy(mcg_engine* e) {
   if (!e) return;
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  for (int i = 0; i < mcg_engine::kMaxSplit - 1; ++i) {
+  for (int i = 0; i < mcg_engine::kMaxSplit - 1; ++i)
     if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
-    if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
-  }
+  for (int i = 0; i < 3; ++i)
+    if (e->ev_probe[i]) (void)hipEventDestroy(e->ev_probe[i]);
+  for (int i = 0; i < mcg_engine::kCandidates; ++i)
+    if (e->cand[i]) (void)hipStreamDestroy(e->cand[i]);
   delete e;
 }
 
@@ -262,6 +301,7 @@ extern "C" int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s_, const floa
   if (k == 1) return trunk_chunk(e, s, img, 0, N, H, W, pyramid, (char*)ws);
   // fork: the side streams start after everything already queued on the caller's stream (the input, the previous consumer of
   // the pyramid buffers); join: the caller's stream continues after every range
+  const std::vector<int>& sides = side_streams_for(e, s);
   const int per = (N + k - 1) / k;
   const size_t part_ws = al256(trunk_layout(e->dt, per, H, W, nullptr).total);
   if (hipEventRecord(e->ev_fork, s) != hipSuccess) { mcg_set_error("mcg_backbone_fpn_forward: hipEventRecord failed"); return MCG_ERR_HIP; }
@@ -269,7 +309,7 @@ extern "C" int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s_, const floa
   for (int i = 0; i < k && rc == MCG_OK; ++i) {
     const int f0 = i * per, n = (N - f0) < per ? (N - f0) : per;
     if (n <= 0) break;
-    hipStream_t si = i == 0 ? s : e->side[i - 1];
+    hipStream_t si = i == 0 ? s : e->cand[sides[i - 1]];
     if (i > 0 && hipStreamWaitEvent(si, e->ev_fork, 0) != hipSuccess) { mcg_set_error("mcg_backbone_fpn_forward: hipStreamWaitEvent failed"); rc = MCG_ERR_HIP; break; }
     rc = trunk_chunk(e, si, img, f0, n, H, W, pyramid, (char*)ws + (size_t)i * part_ws);
     if (i > 0) {  // joined even after a failed launch, so the caller's stream never runs ahead of a side stream

@@ -29,13 +29,20 @@ class ResultGather:
         self.local = torch.zeros(FLOATS_PER_FRAME * frames_per_rank, dtype=torch.float32, device=device)
         self.all = torch.zeros(world * FLOATS_PER_FRAME * frames_per_rank, dtype=torch.float32, device=device) if world > 1 else self.local
 
+    def all_single(self):
+        if not hasattr(self, '_single'):
+            self._single = torch.zeros_like(self.local)
+        return self._single
+
     def local_views(self):
         return _views(self.local, self.n)
 
     def all_gather(self, group=None):
-        if self.world == 1:
-            return self.all
         import torch.distributed as dist
+        if self.world == 1:
+            if dist.is_available() and dist.is_initialized():   # single-rank group: still a real collective call (self-copy)
+                dist.all_gather_into_tensor(self.all_single(), self.local, group=group)
+            return self.all
         dist.all_gather_into_tensor(self.all, self.local, group=group)
         return self.all
 

@@ -4,6 +4,7 @@ over torch device tensors.  PyTorch is used for device memory and streams only; 
 arithmetic runs in the hand-written HIP kernels behind the C-ABI.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
