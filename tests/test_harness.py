@@ -130,3 +130,56 @@ def test_run_annotation_from_files_equals_window_by_window(tmp_path):
             outs.append((det.clone(), o['gaze'][0].clone(), o['gaze'][1:].permute(1, 0, 2).clone()))
         want = harness.video_record(v['id'], *harness.merge_video(plan, outs))
         assert rec == want and len(rec['fusion_gazes']) == len(v['file_names'])
+
+
+def test_dataset_tool_cli_and_sharding():
+    """tools/test_gaze360_gaze.py keeps the reference's command line (its :20-44) and shards whole videos by frame count."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('dataset_tool', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'test_gaze360_gaze.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    a = tool.parse_args(['cfg.py', 'ckpt.pth'])
+    assert (a.json, a.root, a.device) == ('data/gaze360/test.json', 'data/gaze360/test_rawframes/', 'cuda:0')   # the reference's defaults
+    a = tool.parse_args(['cfg.py', 'ckpt.pth', '--json', 'x.json', '--cfg-options', 'model.test_cfg.a=3', 'clip_length=5', 'k=1,2', 'f=true'])
+    assert a.cfg_options == {'model.test_cfg.a': 3, 'clip_length': 5, 'k': [1, 2], 'f': True}
+    videos = [dict(file_names=['f'] * n) for n in (50, 7, 7, 30, 12, 40, 3)]
+    shards = [tool.shard_videos(videos, 3, r) for r in range(3)]
+    assert sorted(i for s in shards for i in s) == list(range(7))
+    loads = [sum(len(videos[i]['file_names']) for i in s) for s in shards]
+    assert max(loads) - min(loads) <= 12 and shards == [sorted(s) for s in shards]
+
+
+@pytest.mark.gpu
+def test_dataset_tool_end_to_end(tmp_path, monkeypatch, capsys):
+    """Checkpoint file + annotation json + PNG frames -> results_<cfg>_<json> with the reference's schema, MAE printed."""
+    import importlib.util
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('dataset_tool', os.path.join(root, 'tools', 'test_gaze360_gaze.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    rs = np.random.RandomState(6)
+    ckpt = str(tmp_path / 'ckpt.pth')
+    torch.save(dict(meta=dict(CLASSES=('face', 'eyes', 'head')),
+                    state_dict={'module.' + k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(0).items()}), ckpt)
+    videos, annos = [], []
+    for vid, L in enumerate((8, 4)):
+        names = []
+        os.makedirs(str(tmp_path / 'frames' / f'v{vid}'))
+        for i in range(L):
+            names.append(f'v{vid}/{i:06d}.png')
+            Image.fromarray(rs.randint(0, 256, (240, 240, 3)).astype(np.uint8)).save(str(tmp_path / 'frames' / names[-1]))
+        videos.append(dict(id=vid + 1, file_names=names))
+        g = rs.randn(L, 3)
+        annos.append(dict(gaze=(g / np.linalg.norm(g, axis=1, keepdims=True)).tolist()))
+    test_json = str(tmp_path / 'test.json')
+    json.dump(dict(videos=videos, annotations=annos), open(test_json, 'w'))
+    monkeypatch.chdir(tmp_path)
+    cfg = os.path.join(root, 'configs', 'mcgaze', 'r50_clip7_gaze360.py')
+    tool.main([cfg, ckpt, '--json', test_json, '--root', str(tmp_path / 'frames'), '--seed', '3', '--anno', test_json, '--batch-clips', '2'])
+    out = capsys.readouterr().out
+    path = tmp_path / 'results' / 'results_r50_clip7_gaze360_test.json'
+    assert path.exists() and 'fusion_gazes mean angular error 360:' in out
+    recs = json.load(open(str(path)))
+    assert [r['video_id'] for r in recs] == [1, 2] and [len(r['fusion_gazes']) for r in recs] == [8, 4]
+    assert set(recs[0]) >= {'video_id', 'category_id', 'fusion_gazes', 'face_bboxes', 'face_gazes', 'face_score', 'eyes_gazes', 'head_gazes'}

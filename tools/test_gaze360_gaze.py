@@ -1,0 +1,107 @@
+#!/usr/bin/env python
+"""Dataset inference with the reference's command line (its tools/test_gaze360_gaze.py:20-44):
+
+    python tools/test_gaze360_gaze.py <config> <checkpoint> --json data/gaze360/test.json --root data/gaze360/test_rawframes/ \
+        [--device cuda:0] [--cfg-options k=v ...] [--precision bf16|fp32] [--batch-clips 64] [--seed S] [--anno gt.json]
+
+Every video of the annotation file is cut into 7-frame windows (stride 4), the frames of each window go through
+cfg.data.test.pipeline on the device (mcgaze_amd.pipeline), all windows run through the HIP engine in batches of --batch-clips
+clips, overlaps are merged per video and results/results_<config>_<json> is written with the reference's schema
+(mcgaze_amd.harness).  With --anno the MAE of tools/calculate_mae_gaze360.py / calculate_mae_l2cs.py is printed too
+(mcgaze_amd.metric).  Under torch.distributed.run the videos are sharded over the ranks by frame count and rank 0 writes the file.
+--seed fixes the crop draws of CenterCrop(crop_type='relative_range'), which the reference leaves to the unseeded global RNG
+(SURVEY.md section 5)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcgaze_amd import harness, init_detector, metric  # noqa: E402
+from mcgaze_amd.pipeline import DevicePipeline  # noqa: E402
+
+
+def parse_value(v):
+    for cast in (int, float):
+        try:
+            return cast(v)
+        except ValueError:
+            pass
+    if v.lower() in ('true', 'false'):
+        return v.lower() == 'true'
+    if v.startswith('[') or v.startswith('('):
+        return eval(v, {}, {})
+    return [parse_value(x) for x in v.split(',')] if ',' in v else v
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('config', help='Config file')
+    ap.add_argument('checkpoint', help='Checkpoint file')
+    ap.add_argument('--json', default='data/gaze360/test.json', help='Path to gaze test json file')
+    ap.add_argument('--root', default='data/gaze360/test_rawframes/', help='Path to image file')
+    ap.add_argument('--device', default='cuda:0', help='Device used for inference')
+    ap.add_argument('--cfg-options', nargs='+', default=None, help='k=v overrides merged into the config (mmcv DictAction syntax)')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--batch-clips', type=int, default=64)
+    ap.add_argument('--seed', type=int, default=None)
+    ap.add_argument('--anno', default=None, help='ground-truth annotation json: print the MAE')
+    ap.add_argument('--setting', default=None, choices=['gaze360', 'l2cs'], help='metric variant (default: from the config name)')
+    a = ap.parse_args(argv)
+    if a.cfg_options is not None:
+        a.cfg_options = {kv.split('=', 1)[0]: parse_value(kv.split('=', 1)[1]) for kv in a.cfg_options}
+    return a
+
+
+def shard_videos(videos, world, rank):
+    """Whole videos per rank (the overlap merge needs all windows of a video together), balanced by frame count."""
+    order = sorted(range(len(videos)), key=lambda i: -len(videos[i]['file_names']))
+    load, mine = [0] * world, []
+    for i in order:
+        r = min(range(world), key=lambda k: load[k])
+        load[r] += len(videos[i]['file_names'])
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    device = a.device if world == 1 else f'cuda:{local}'
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+    print(time.strftime('%Y-%m-%d %H:%M:%S', time.localtime(time.time())))
+    model = init_detector(a.config, a.checkpoint, device=device, cfg_options=a.cfg_options, precision=a.precision)
+    pipe = DevicePipeline(model.cfg.data.test.pipeline)
+    anno = json.load(open(a.json))
+    idx = shard_videos(anno['videos'], world, rank)
+    rng = np.random.RandomState(a.seed + rank) if a.seed is not None else None
+    recs = harness.run_annotation(model.engine(), dict(videos=[anno['videos'][i] for i in idx]), a.root, pipe, batch_clips=a.batch_clips, rng=rng)
+    if world > 1:
+        import torch.distributed as dist
+        parts = [None] * world
+        dist.all_gather_object(parts, list(zip(idx, recs)))
+        merged = dict(p for part in parts for p in part)
+        recs = [merged[i] for i in range(len(anno['videos']))]
+    if rank == 0:
+        path = harness.dump_results(recs, a.config, a.json)
+        print('Done', path)
+        if a.anno:
+            setting = a.setting or ('l2cs' if 'l2cs' in os.path.basename(a.config) else 'gaze360')
+            metric.gaze_error(recs, json.load(open(a.anno)), 'fusion_gazes', setting=setting)
+    print(time.strftime('%Y-%m-%d %H:%M:%S', time.localtime(time.time())))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
