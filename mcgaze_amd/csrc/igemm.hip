@@ -2,6 +2,7 @@
 // (stem input packing, 3x3/s2 max-pool, NCHW<->NHWC).
 #include "igemm_dma.hpp"
 #include "stem_fused.hpp"
+#include "conv3x3_c64.hpp"
 
 #include <stdarg.h>
 #include <stdlib.h>
@@ -241,6 +242,20 @@ extern "C" int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d) {
     p.xs2_w = d->Cin2; p.xs2_h = (long long)d->W2 * d->Cin2; p.xs2_n = (long long)d->H2 * d->W2 * d->Cin2;
   }
   p.splitk = 1; p.tiles_per_slice = 1 << 30;
+  if (dt == MCG_BF16 && d->bias && conv3x3_c64_applicable(d->KH, d->KW, d->stride, d->pad, d->Cin, d->Cout, p.res_mode != MCG_RES_NONE, d->x2 != nullptr) &&
+      env_int("MCG_C64", 1)) {  // layer1's conv2: window staged once, nine taps by address (conv3x3_c64.hpp); bit-identical
+    ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
+    if (rec) {
+      rec->cfg = 32;
+      rec->shape[0] = p.M; rec->shape[1] = 64; rec->shape[2] = 576;
+      rec->flops = 2.0 * p.M * 64 * 576;
+      (void)hipEventRecord(rec->a, (hipStream_t)s);
+    }
+    const int rc = launch_conv3x3_c64((hipStream_t)s, d->x, d->w, d->bias, d->y, d->N, d->H, d->W, d->relu);
+    if (rec) (void)hipEventRecord(rec->b, (hipStream_t)s);
+    if (rc) { mcg_set_error("conv3x3_c64 launch failed"); return MCG_ERR_HIP; }
+    return MCG_OK;
+  }
   return launch_igemm((hipStream_t)s, dt, p, 1);
 }
 

@@ -151,6 +151,24 @@ def test_every_dma_tile_is_bit_identical(eng, shape, monkeypatch):
         assert torch.equal(y.view(torch.int16), outs[9].view(torch.int16)), tile
 
 
+@pytest.mark.parametrize('shape', [(3, 56, 56), (2, 28, 84), (1, 9, 5), (2, 80, 112)])
+@pytest.mark.parametrize('relu', [True, False])
+def test_conv3x3_c64_is_bit_identical_to_the_generic_kernel(eng, shape, relu, monkeypatch):
+    """conv3x3_c64.hpp (layer1's conv2: input window staged once, taps by address) keeps the generic kernel's K order: same bits,
+    incl. maps that are not a multiple of its 8 x 28 tile and maps smaller than one tile."""
+    n, h, w = shape
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(n, h, w, 64, generator=g).to(torch.bfloat16).to('cuda:0')
+    wt = (torch.randn(64, 3, 3, 64, generator=g) / 24.0).to(torch.bfloat16).to('cuda:0')
+    b = torch.randn(64, generator=g).to('cuda:0')
+    monkeypatch.setenv('MCG_C64', '0')
+    a = eng.conv2d(x, wt, b, stride=1, pad=1, relu=relu).clone()
+    monkeypatch.setenv('MCG_C64', '1')
+    c = eng.conv2d(x, wt, b, stride=1, pad=1, relu=relu)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int16), c.view(torch.int16))
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 96), (3, 224, 224), (1, 320, 448), (2, 36, 52)])
 def test_fused_stem_is_bit_identical_to_the_three_kernel_path(eng, sd, shape, monkeypatch):
     """stem_fused.hpp keeps the unfused path's packing and K order, so not even rounding may differ -- incl. sizes whose
