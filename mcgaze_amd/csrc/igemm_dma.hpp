@@ -81,7 +81,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   constexpr int PIECES_PER_WAVE = A_PIECES + B_PIECES;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N, TM = WTM / 32, TN = WTN / 32;
   constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB, STAGE = A_BYTES + B_BYTES;
-  constexpr int LDS_BYTES = STAGES * STAGE;
+  constexpr int RING_BYTES = STAGES * STAGE;
+  // the 256x128 / 8-wave tile rounds its 48 KiB ring up to 64 KiB (still two workgroups per CU): two wave-rows of epilogue staging
+  // per pass instead of one halves the epilogue's barriers
+  constexpr int LDS_BYTES = (BM == 256 && BN == 128 && NW == 8 && RING_BYTES == 49152 && MINW <= 2) ? 65536 : RING_BYTES;
   // epilogue passes: as many wave-rows (WTM output rows each) per pass as fit the ring's footprint
   constexpr int WR_FIT = LDS_BYTES / (WTM * BN * 4);
   // ... rounded down to a divisor of WAVES_M: a last pass with fewer wave-rows than the others would store stale staging rows
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   constexpr int CPRO = BN / EPC;                         // output chunks per row
   constexpr int CH_PER_THREAD = PASS_ROWS * CPRO / NT;   // output chunks per thread per pass
   // register budget: prefetch the first pass's residual before the K loop only when it does not cost occupancy
-  constexpr bool EARLY_RES = TM * TN * 16 + CH_PER_THREAD * 4 <= 144 && MINW <= 2;
+  constexpr bool EARLY_RES = TM * TN * 16 + CH_PER_THREAD * 4 <= 144 && MINW <= 2 && !(LDS_BYTES != RING_BYTES);
   static_assert(A_PIECES >= 1 && B_PIECES >= 1 && A_PIECES * RPP * NW == BM && B_PIECES * RPP * NW == BN, "tile / wave count mismatch");
   static_assert(STAGES >= 2, "ring needs >= 2 stages");
   static_assert(PIECES_PER_WAVE * (STAGES - 2) <= 63, "vmcnt field");

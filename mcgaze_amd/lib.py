@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmcgaze_hip.so')
+LIB_PATH = os.environ.get('MCGAZE_LIB') or os.path.join(_HERE, 'libmcgaze_hip.so')   # MCGAZE_LIB: A/B a second build on one box
 
 MCG_OK = 0
 MCG_F32, MCG_BF16 = 0, 1
