@@ -232,7 +232,7 @@ class PipelinedRunner:
         self.e, self.N, self.H, self.W, self.T, self.chunk = engine, num_frames, H, W, clip_length, chunk_frames
         dev, lib, h = engine.device, engine.lib, engine._handle
         # the decoder's short launches get the high-priority queue so they slot in between the trunk's long kernels
-        self.sa, self.sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)
+        self.sa, self.sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=int(os.environ.get('MCG_DECODER_PRIORITY', '-1')))
         self.pyr = [[torch.empty(num_frames, (H // 4) >> i, (W // 4) >> i, 256, dtype=engine.dtype, device=dev) for i in range(4)] for _ in range(2)]
         self.tabs = [(C.c_void_p * 4)(*[p.data_ptr() for p in lvl]) for lvl in self.pyr]
         self.trunk_ws = _ws(lib.mcg_trunk_workspace_bytes(h, num_frames, H, W, chunk_frames), dev)
