@@ -25,6 +25,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FLOPS_PER_CLIP_TRUNK = 97.01e9    # backbone + FPN only
 FLOPS_PER_CLIP = 99.55e9          # 2*MAC over convs + linears + bmms, 7x3x224x224 clip
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
@@ -49,6 +50,9 @@ def parse():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--chunk-frames', type=int, default=0)
+    ap.add_argument('--workload', default='full', choices=['full', 'backbone_fpn'],
+                    help="'full' = BASELINE.json configs[2] (the metric's configuration); 'backbone_fpn' = configs[1], the trunk alone "
+                         '(use --clips-per-gpu 32 for its 32 x 7 frames)')
     ap.add_argument('--pipeline', type=int, default=1, choices=[0, 1],
                     help='1: two-deep batch pipeline (decoder of step k overlaps trunk of step k+1 on a second stream; '
                          'every batch is fully processed inside the timed region), 0: one stream, strictly serial')
@@ -109,7 +113,7 @@ def main():
     from mcgaze_amd.engine import PipelinedRunner
     gathers = [ResultGather(N, world, dev) for _ in range(2)]   # results double-buffered like the pipeline
     outs = [g.local_views() for g in gathers]                    # the engine writes straight into the fused exchange buffers
-    runner = PipelinedRunner(eng, N, a.size, a.size, T, a.chunk_frames) if a.pipeline else None
+    runner = PipelinedRunner(eng, N, a.size, a.size, T, a.chunk_frames) if a.pipeline and a.workload == 'full' else None
     eng.forward(img, T, chunk_frames=a.chunk_frames, out=outs[0])
     state = {'k': 0}
 
@@ -119,6 +123,9 @@ def main():
     gathered = [None, None]
 
     def step():
+        if a.workload == 'backbone_fpn':
+            eng.backbone_fpn(img, a.chunk_frames)
+            return
         slot = state['k'] & 1
         state['k'] += 1
         cur = torch.cuda.current_stream(dev)
@@ -158,7 +165,10 @@ def main():
         os.environ['MCG_TRUNK_STREAMS'] = '1'
         cnt = C.c_int()
         L.check(lib.mcg_profile_start(4096), 'mcg_profile_start')
-        eng.forward(img, T, chunk_frames=a.chunk_frames, out=outs[0])
+        if a.workload == 'full':
+            eng.forward(img, T, chunk_frames=a.chunk_frames, out=outs[0])
+        else:
+            eng.backbone_fpn(img, a.chunk_frames)
         torch.cuda.synchronize(dev)
         L.check(lib.mcg_profile_stop(C.byref(cnt), None, None, None, None, 4096), 'mcg_profile_stop')
         launches = cnt.value
@@ -209,19 +219,20 @@ def main():
         elapsed = float(t.item())
     if rank == 0:
         total_clips = B * world * a.steps
+        flops_per_clip = FLOPS_PER_CLIP if a.workload == 'full' else FLOPS_PER_CLIP_TRUNK
         value = total_clips / elapsed
         line = {
             'metric': 'clips/sec (7x3x224x224)', 'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic (seeded N(0,1) clips, random-init weights, resident in HBM)',
-            'config': {'workload': f'full multiclue_gaze_r50 forward (R-50 + FPN + 4 decoder stages + gaze head), '
+            'config': {'workload': ('full multiclue_gaze_r50 forward (R-50 + FPN + 4 decoder stages + gaze head), ' if a.workload == 'full' else 'R-50 backbone + FPN only (BASELINE.json configs[1]), ') +
                                    f'{B} clips/GPU x {T} frames x 3x{a.size}x{a.size}, {B * world} clips/step',
                        'clips_per_gpu': B, 'clip_length': T, 'global_clips': B * world, 'chunk_frames': a.chunk_frames,
                        'parallelism': f'dp{world} (clips sharded by rank, one fused all_gather of results per step)' if world > 1 else 'single GPU',
-                       'batch_pipeline': 'decoder(step k) overlaps trunk(step k+1) on a second HIP stream; all K batches complete inside the timed region' if a.pipeline else 'none (serial)',
+                       'batch_pipeline': 'decoder(step k) overlaps trunk(step k+1) on a second HIP stream; all K batches complete inside the timed region' if (a.pipeline and a.workload == 'full') else 'none (serial)',
                        'trunk_streams': int(os.environ.get('MCG_TRUNK_STREAMS', '2'))},
-            'model_tflops': round(value * FLOPS_PER_CLIP / 1e12, 1),
-            'frac_of_bf16_mfma_peak': round(value * FLOPS_PER_CLIP / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+            'model_tflops': round(value * flops_per_clip / 1e12, 1),
+            'frac_of_bf16_mfma_peak': round(value * flops_per_clip / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             'roofline': roofline,
         }
         if world == 1 and a.cpu_seconds > 0:
