@@ -68,6 +68,16 @@ static const std::vector<int>& side_streams_for(mcg_engine* e, hipStream_t s) {
   good.insert(good.end(), rest.begin(), rest.end());  // fall back to serialised candidates rather than fail
   return e->side_of.emplace(s, good).first->second;
 }
+// Frames per launch sequence are capped so that the largest activation of a range ([n, H/4, W/4, 256]) stays inside the 2 GiB
+// window of the contraction kernel's buffer descriptors (beyond it every conv would fall back to the slower register-staged
+// kernel): 1337 frames at 224x224 bf16.  MCG_MAX_RANGE_FRAMES lowers the cap (tests).
+static int range_frame_cap(mcg_dtype dt, int H, int W) {
+  const long long per_frame = (long long)(H / 4) * (W / 4) * 256 * (dt == MCG_BF16 ? 2 : 4);
+  long long cap = 0x7FFFFF00ll / (per_frame > 0 ? per_frame : 1);
+  const char* v = getenv("MCG_MAX_RANGE_FRAMES");
+  if (v && atoi(v) > 0 && atoi(v) < cap) cap = atoi(v);
+  return cap < 1 ? 1 : (cap > 0x7fffffff ? 0x7fffffff : (int)cap);
+}
 static const int kMinFramesPerRange = 56;  // below this a range's kernels no longer fill the chip on their own
 static int trunk_ranges(int frames) {
   const char* v = getenv("MCG_TRUNK_STREAMS");  // read per call (bench.py samples per-launch durations with 1)
@@ -261,9 +271,10 @@ extern "C" size_t mcg_trunk_workspace_bytes(const mcg_engine* e, int N, int H, i
   if (chunk < N) return trunk_layout(e->dt, chunk, H, W, nullptr).total;
   // whole batch: one layout per concurrent frame range, sized for the maximum split so the answer does not depend on the environment
   size_t total = 0;
+  const int cap = range_frame_cap(e->dt, H, W);
   for (int k = 1; k <= mcg_engine::kMaxSplit; ++k) {
-    size_t t = 0;
-    for (int i = 0; i < k; ++i) t += al256(trunk_layout(e->dt, (N + k - 1) / k, H, W, nullptr).total);
+    const int per = (N + k - 1) / k < cap ? (N + k - 1) / k : cap;
+    const size_t t = (size_t)k * al256(trunk_layout(e->dt, per, H, W, nullptr).total);
     if (t > total) total = t;
   }
   return total;
@@ -298,25 +309,30 @@ extern "C" int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s_, const floa
     return MCG_OK;
   }
   const int k = trunk_ranges(N);
-  if (k == 1) return trunk_chunk(e, s, img, 0, N, H, W, pyramid, (char*)ws);
+  const int cap = range_frame_cap(e->dt, H, W);
+  const int per = (N + k - 1) / k < cap ? (N + k - 1) / k : cap;
+  if (k == 1) {
+    for (int f0 = 0; f0 < N; f0 += per) MCG_TRY(trunk_chunk(e, s, img, f0, (N - f0) < per ? (N - f0) : per, H, W, pyramid, (char*)ws));
+    return MCG_OK;
+  }
   // fork: the side streams start after everything already queued on the caller's stream (the input, the previous consumer of
-  // the pyramid buffers); join: the caller's stream continues after every range
+  // the pyramid buffers); join: the caller's stream continues after every range.  Range i owns stream i and workspace slot i;
+  // a batch larger than k capped ranges takes several rounds on the same streams and slots (in order per stream).
   const std::vector<int>& sides = side_streams_for(e, s);
-  const int per = (N + k - 1) / k;
   const size_t part_ws = al256(trunk_layout(e->dt, per, H, W, nullptr).total);
   if (hipEventRecord(e->ev_fork, s) != hipSuccess) { mcg_set_error("mcg_backbone_fpn_forward: hipEventRecord failed"); return MCG_ERR_HIP; }
   int rc = MCG_OK;
-  for (int i = 0; i < k && rc == MCG_OK; ++i) {
-    const int f0 = i * per, n = (N - f0) < per ? (N - f0) : per;
-    if (n <= 0) break;
+  for (int i = 1; i < k; ++i)
+    if (hipStreamWaitEvent(e->cand[sides[i - 1]], e->ev_fork, 0) != hipSuccess) { mcg_set_error("mcg_backbone_fpn_forward: hipStreamWaitEvent failed"); return MCG_ERR_HIP; }
+  for (int f0 = 0, i = 0; f0 < N && rc == MCG_OK; f0 += per, i = (i + 1) % k) {
     hipStream_t si = i == 0 ? s : e->cand[sides[i - 1]];
-    if (i > 0 && hipStreamWaitEvent(si, e->ev_fork, 0) != hipSuccess) { mcg_set_error("mcg_backbone_fpn_forward: hipStreamWaitEvent failed"); rc = MCG_ERR_HIP; break; }
-    rc = trunk_chunk(e, si, img, f0, n, H, W, pyramid, (char*)ws + (size_t)i * part_ws);
-    if (i > 0) {  // joined even after a failed launch, so the caller's stream never runs ahead of a side stream
-      if (hipEventRecord(e->ev_join[i - 1], si) != hipSuccess || hipStreamWaitEvent(s, e->ev_join[i - 1], 0) != hipSuccess) {
-        mcg_set_error("mcg_backbone_fpn_forward: join failed");
-        rc = rc == MCG_OK ? MCG_ERR_HIP : rc;
-      }
+    rc = trunk_chunk(e, si, img, f0, (N - f0) < per ? (N - f0) : per, H, W, pyramid, (char*)ws + (size_t)i * part_ws);
+  }
+  for (int i = 1; i < k; ++i) {  // joined even after a failed launch, so the caller's stream never runs ahead of a side stream
+    hipStream_t si = e->cand[sides[i - 1]];
+    if (hipEventRecord(e->ev_join[i - 1], si) != hipSuccess || hipStreamWaitEvent(s, e->ev_join[i - 1], 0) != hipSuccess) {
+      mcg_set_error("mcg_backbone_fpn_forward: join failed");
+      rc = rc == MCG_OK ? MCG_ERR_HIP : rc;
     }
   }
   return rc;

@@ -194,3 +194,22 @@ def test_fp32_engine_matches_oracle_on_unusual_shapes(engines, B, T, H, W):
     np.testing.assert_allclose(out['boxes'].cpu().numpy(), want_det[..., :4].numpy(), atol=5e-2, rtol=1e-4)
     bf = engines['bf16'].forward(torch.from_numpy(img).to('cuda:0'), T)
     assert torch.isfinite(bf['gaze']).all() and (orc.yaw_pitch(bf['gaze'][0].cpu()) - orc.yaw_pitch(want_gaze['gaze_score'])).abs().max().item() < BF16_TOL
+
+
+def test_frame_range_cap_and_stream_split_do_not_change_results(engines, monkeypatch):
+    """The trunk runs as concurrent frame ranges, capped so that no activation outgrows the 2 GiB descriptor window; a batch
+    beyond k capped ranges takes several rounds.  Forcing a tiny cap (many rounds), one stream, or four must all give the bits
+    of the default."""
+    T, B = 7, 40
+    img = torch.from_numpy(synth.make_clips(77, B, T, 64, 96)).to('cuda:0')
+    e = engines['bf16']
+    ref = {k: v.clone() for k, v in e.forward(img, T).items()}
+    for env in (dict(MCG_MAX_RANGE_FRAMES='40'), dict(MCG_TRUNK_STREAMS='1'), dict(MCG_TRUNK_STREAMS='4'), dict(MCG_TRUNK_STREAMS='3', MCG_MAX_RANGE_FRAMES='57')):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = e.forward(img, T)
+        torch.cuda.synchronize()
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), (env, k)
+        for k in env:
+            monkeypatch.delenv(k)
