@@ -91,6 +91,45 @@ def test_conv2d(eng, dtype, case):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+def test_conv2d_randomized_shapes(eng, dtype):
+    """Seeded sweep over the contraction kernel's paths: ragged row / channel tiles, 1x1 / 3x3 / 5x5 taps, stride 1-2, padding 0-2,
+    channel counts from 32 to 640, every residual mode, single-pixel maps and row counts below one tile."""
+    rs = np.random.RandomState(2024)
+    dev = 'cuda:0'
+    for trial in range(36):
+        k = int(rs.choice([1, 1, 3, 3, 5]))
+        stride = int(rs.choice([1, 1, 2]))
+        pad = int(rs.choice([0, k // 2])) if k > 1 else 0
+        cin = int(rs.choice([32, 64, 96, 128, 256, 320]))
+        cout = int(rs.choice([32, 64, 72, 128, 256, 640]))
+        N = int(rs.randint(1, 5))
+        H, W = int(rs.randint(max(k, 1), 23)), int(rs.randint(max(k, 1), 23))
+        relu = bool(rs.randint(2))
+        g = torch.Generator().manual_seed(5000 + trial)
+        x = torch.randn(N, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+        b = torch.randn(cout, generator=g)
+        q = (lambda t: t.to(dtype).float())
+        ref = F.conv2d(q(x), q(w), b, stride=stride, padding=pad)
+        mode, res = int(rs.randint(3)), None
+        if mode == 1:
+            res = torch.randn(ref.shape, generator=g)
+            ref = ref + q(res)
+        elif mode == 2:
+            hr, wr = max(ref.shape[2] // 2, 1), max(ref.shape[3] // 2, 1)
+            res = torch.randn(N, cout, hr, wr, generator=g)
+            ref = ref + F.interpolate(q(res), size=ref.shape[2:], mode='nearest')
+        if relu:
+            ref = F.relu(ref)
+        nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev)
+        y = eng.conv2d(nhwc(x), w.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev), b.to(dev), stride=stride, pad=pad, relu=relu,
+                       residual=nhwc(res) if res is not None else None, residual_mode=mode)
+        torch.cuda.synchronize()
+        err = scale_err(y.permute(0, 3, 1, 2), ref)
+        assert err < TOL[dtype], (trial, (N, H, W, cin, cout, k, stride, pad, relu, mode), err)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('stride2', [1, 2])
 def test_conv3_plus_downsample_as_one_k_concatenated_conv(eng, dtype, stride2):
     """relu(conv3(o2) + downsample(x)) (resnet.py:289-298, res_layer.py:51-61) == one 1x1 conv over [o2 | x@stride]."""
