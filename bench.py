@@ -38,7 +38,8 @@ CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,
              19: 'igemm_dma_kernel<bf16,256,256,64,4,2,3>', 24: 'igemm_dma_kernel<bf16,128,128,64,2,2,2>',
              25: 'igemm_dma_kernel<bf16,256,128,64,4,2,2>', 26: 'igemm_dma_kernel<bf16,128,128,64,2,2,3>',
              27: 'igemm_dma_kernel<bf16,128,128,64,4,2,2>', 28: 'igemm_dma_kernel<bf16,256,256,64,4,4,3>',
-             29: 'igemm_dma_kernel<bf16,256,256,64,4,4,2>', 30: 'igemm_dma_kernel<bf16,256,256,128,4,4,2>', 31: 'igemm_dma_kernel<bf16,128,128,64,4,2,3>', 32: 'conv3x3_c64_kernel'}
+             29: 'igemm_dma_kernel<bf16,256,256,64,4,4,2>', 30: 'igemm_dma_kernel<bf16,256,256,128,4,4,2>', 31: 'igemm_dma_kernel<bf16,128,128,64,4,2,3>', 32: 'igemm_dma_kernel<bf16,256,128,64,4,2,3> (<=128 VGPRs)', 40: 'conv3x3_c64_kernel'}
+
 
 def parse():
     ap = argparse.ArgumentParser()

@@ -126,7 +126,8 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   // linears.  MCG_TILE >= 0 overrides.
   //   0 = 128x128 4w 4 stages   1 = 256x128 4w 3st   2 = 256x128 8w 3st   3 = 256x256 8w 3st
   //   8 = 128x128 4w 2st        9 = 256x128 8w 2st   10 = 128x128 4w 3st   12 = 256x256 16w 3st (one 1024-thread workgroup per CU)
-  //   11 = 128x128 8w 2st      15 = 128x128 8w 3st
+  //   11 = 128x128 8w 2st      15 = 128x128 8w 3st   16 = 256x128 8w 3st capped at 128 VGPRs: 5-10 % faster than 9 / 12 on the K = 512..2304,
+  //   N <= 256 layers one launch at a time, but not once two frame ranges run concurrently (profiles/r01_i_tile16.md) -- not chosen
   int tile = 8;
   if (dma && p.Cout > 64) {
     const long long blocks9 = (long long)((p.M + 255) / 256) * ((p.Cout + 127) / 128);
@@ -157,6 +158,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     else if (tile == 10) launch_dma<T, 128, 128, 64, 2, 2, 3>(s, p, groups);
     else if (tile == 11) launch_dma<T, 128, 128, 64, 4, 2, 2>(s, p, groups);
     else if (tile == 15) launch_dma<T, 128, 128, 64, 4, 2, 3>(s, p, groups);
+    else if (tile == 16) launch_dma<T, 256, 128, 64, 4, 2, 3, 4>(s, p, groups);
     else if (tile == 12) launch_dma<T, 256, 256, 64, 4, 4, 3, 4>(s, p, groups);
     else if (tile == 13) launch_dma<T, 256, 256, 64, 4, 4, 2, 4>(s, p, groups);
     else if (tile == 14 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 4, 2, 4>(s, p, groups);
@@ -246,7 +248,7 @@ extern "C" int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d) {
       env_int("MCG_C64", 1)) {  // layer1's conv2: window staged once, nine taps by address (conv3x3_c64.hpp); bit-identical
     ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
     if (rec) {
-      rec->cfg = 32;
+      rec->cfg = 40;
       rec->shape[0] = p.M; rec->shape[1] = 64; rec->shape[2] = 576;
       rec->flops = 2.0 * p.M * 64 * 576;
       (void)hipEventRecord(rec->a, (hipStream_t)s);
