@@ -8,6 +8,7 @@
 // workgroups of one range's kernel (layer3 at 14x14 has 343 output tiles for 256 CUs) overlaps with the other range's
 // kernels: 448 frames 9.36 -> 8.75 ms (tools/trunk_two_streams.py).
 #include "igemm.hpp"
+#include "bottleneck_fused.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -201,9 +202,21 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
       const mcg_conv_weights& c1 = e->convs[ci], &c2 = e->convs[ci + 1], &c3 = e->convs[ci + 2];
       const bool has_ds = b == 0;
       const int ho = (h + 2 * c2.pad - c2.k) / c2.stride + 1, wo = (w + 2 * c2.pad - c2.k) / c2.stride + 1;
+      void* y = (b == e->blocks[l] - 1) ? (void*)t.c[l] : (x == t.xa ? (void*)t.xb : (void*)t.xa);
+      const char* fb = getenv("MCG_FUSED_BLOCK");  // read per call: the bit-identity test flips it
+      if (dt == MCG_BF16 && !has_ds && fb && fb[0] == '1' && c1.cin == 256 && c1.cout == 64 && c1.k == 1 && c2.cin == 64 && c2.cout == 64 &&
+          c2.k == 3 && c2.stride == 1 && c2.pad == 1 && c3.cin == 64 && c3.cout == 256 && c3.k == 1 && c1.bias && c2.bias && c3.bias) {
+        // identity bottleneck of layer1 as ONE kernel (bottleneck_fused.hpp): the 64-channel intermediates stay on the CU
+        if (launch_bottleneck_fused(s, x, y, c1.w, c1.bias, c2.w, c2.bias, c3.w, c3.bias, n, h, w)) {
+          mcg_set_error("bottleneck_fused launch failed");
+          return MCG_ERR_HIP;
+        }
+        x = y;
+        ci += 3;
+        continue;
+      }
       MCG_TRY(conv_call(s, dt, c1, x, n, h, w, t.o1, 1, nullptr, MCG_RES_NONE, 0, 0));
       MCG_TRY(conv_call(s, dt, c2, t.o1, n, h, w, t.o2, 1, nullptr, MCG_RES_NONE, 0, 0));
-      void* y = (b == e->blocks[l] - 1) ? (void*)t.c[l] : (x == t.xa ? (void*)t.xb : (void*)t.xa);
       if (has_ds && e->c3_ds[l].w) {
         // conv3 and the downsample conv as ONE K-concatenated GEMM: relu([o2 | x@stride] . [W3 | Wd]^T + b3 + bd);
         // the downsample output never goes to HBM and conv3 reads no residual.

@@ -213,3 +213,18 @@ def test_frame_range_cap_and_stream_split_do_not_change_results(engines, monkeyp
             assert torch.equal(out[k], ref[k]), (env, k)
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_fused_bottleneck_is_bit_identical(engines, monkeypatch):
+    """bottleneck_fused.hpp (layer1's identity blocks as one kernel each) against the three launches it replaces: the pyramid the
+    trunk produces must not change by a bit -- on a frame size that is not a multiple of its 8 x 28 tile as well."""
+    e = engines['bf16']
+    for shape in ((3, 224, 224), (2, 96, 160)):
+        img = torch.from_numpy(synth.make_clips(31, 1, *shape)).to('cuda:0')
+        monkeypatch.setenv('MCG_FUSED_BLOCK', '0')
+        ref = [p.clone() for p in e.backbone_fpn(img)]
+        monkeypatch.setenv('MCG_FUSED_BLOCK', '1')
+        out = e.backbone_fpn(img)
+        torch.cuda.synchronize()
+        for a, b in zip(ref, out):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), shape
