@@ -115,7 +115,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   // MCG_FORCE_NARROW=1 its 64-byte K slices, MCG_TILE=1 the 256x128 DMA tile.
   static const int use_v1 = env_int("MCG_IGEMM", 0), force_narrow = env_int("MCG_FORCE_NARROW", 0), wide16 = env_int("MCG_WIDE16", 1);
   const int big_tile = env_int("MCG_TILE", -1);
-  static const int t12_min = env_int("MCG_T12_MIN", 320), t9_min = env_int("MCG_T9_MIN", 300);  // read per call: tests and tools/tile_sweep.sh switch tiles inside one process
+  static const int t12_min = env_int("MCG_T12_MIN", 320), t9_min = env_int("MCG_T9_MIN", 300), t14_min = env_int("MCG_T14_MIN", 1000);  // read per call: tests and tools/tile_sweep.sh switch tiles inside one process
   const bool dma = ES == 2 && !use_v1 && dma_eligible(p, ES);
   const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0 && (!p.x2 || (p.Cin2 * ES) % 128 == 0);
   MCG_CHECK_ARG((p.Cin * ES) % 64 == 0 && (!p.x2 || (p.Cin2 * ES) % 64 == 0), "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
@@ -128,12 +128,13 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   //   8 = 128x128 4w 2st        9 = 256x128 8w 2st   10 = 128x128 4w 3st   12 = 256x256 16w 3st (one 1024-thread workgroup per CU)
   //   11 = 128x128 8w 2st      15 = 128x128 8w 3st   16 = 256x128 8w 3st capped at 128 VGPRs: 5-10 % faster than 9 / 12 on the K = 512..2304,
   //   N <= 256 layers one launch at a time, but not once two frame ranges run concurrently (profiles/r01_i_tile16.md) -- not chosen
+  //   14 = 256x256 16w, 128-byte K slices, 2st: half the barriers of 12 per K; +3 % on the K >= 1000 layers (3x3s, layer3/4 conv1), MCG_T14_MIN
   int tile = 8;
   if (dma && p.Cout > 64) {
     const long long blocks9 = (long long)((p.M + 255) / 256) * ((p.Cout + 127) / 128);
     const long long Kdim = (long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
     if (big_tile >= 0) tile = big_tile;
-    else if (wide16 && p.Cout % 256 == 0 && Kdim >= 384 && blocks9 >= t12_min) tile = 12;  // deep K, full 256-wide N blocks: fewest LDS-DMA bytes per FLOP
+    else if (wide16 && p.Cout % 256 == 0 && Kdim >= 384 && blocks9 >= t12_min) tile = (t14_min > 0 && Kdim >= t14_min && (p.Cin * ES) % 128 == 0 && !p.x2) ? 14 : 12;  // deep K, full 256-wide N blocks: fewest LDS-DMA bytes per FLOP
     else tile = blocks9 >= t9_min ? 9 : (p.M <= 4096 ? 11 : 15);  // few rows: 128x128 tiles with 8 waves (32x64 wave tiles, ~85 VGPRs)
   }
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
