@@ -128,6 +128,8 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   //   8 = 128x128 4w 2st        9 = 256x128 8w 2st   10 = 128x128 4w 3st   12 = 256x256 16w 3st (one 1024-thread workgroup per CU)
   //   11 = 128x128 8w 2st      15 = 128x128 8w 3st   16 = 256x128 8w 3st capped at 128 VGPRs: 5-10 % faster than 9 / 12 on the K = 512..2304,
   //   N <= 256 layers one launch at a time, but not once two frame ranges run concurrently (profiles/r01_i_tile16.md) -- not chosen
+  //   21 / 22 = 256x256 8w (64x128 / 128x64 wave tiles, fragments double-buffered in registers), 128-byte K slices, 2st: 2-3 % behind 14
+  //   at the same package power (profiles/r01_j_power.md) -- sweep options only
   //   14 = 256x256 16w, 128-byte K slices, 2st: half the barriers of 12 per K; +3 % on the K >= 1000 layers (3x3s, layer3/4 conv1), MCG_T14_MIN
   int tile = 8;
   if (dma && p.Cout > 64) {
@@ -163,6 +165,8 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     else if (tile == 12) launch_dma<T, 256, 256, 64, 4, 4, 3, 4>(s, p, groups);
     else if (tile == 13) launch_dma<T, 256, 256, 64, 4, 4, 2, 4>(s, p, groups);
     else if (tile == 14 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 4, 2, 4>(s, p, groups);
+    else if (tile == 21 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 2, 2, 2>(s, p, groups);
+    else if (tile == 22 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 2, 4, 2, 2>(s, p, groups);
     else launch_dma<T, 128, 128, 64, 2, 2, 4>(s, p, groups);
   } else if (p.Cout <= 64) {
     if (wide) launch_cfg<T, 128, 64, 128, 4, 1>(s, p, groups);

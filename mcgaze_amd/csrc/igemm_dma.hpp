@@ -275,19 +275,53 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
     fa[j2] = smem + (wm * WTM + (lane & 31)) * BKB + cb;
     fb[j2] = smem + A_BYTES + (wn * WTN + (lane & 31)) * BKB + cb;
   }
+  // Big wave tiles (>= 8 MFMAs per K-step) run two waves per SIMD: too few to hide an LDS round trip per K-step behind the other
+  // waves, so the fragments are double-buffered in registers -- step j+1's reads are issued before step j's MFMAs.
+  constexpr bool SWP = TM * TN >= 8 && CPR / 2 >= 2;
   auto compute_tile = [&](auto imm_c, uint32_t roff) {
     constexpr int IMM = decltype(imm_c)::value;
+    if constexpr (SWP) {
+      uint4 af[2][TM], bf[2][TN];
+      auto load = [&](auto j2c) {
+        constexpr int J2 = decltype(j2c)::value;
 #pragma unroll
-    for (int j2 = 0; j2 < CPR / 2; ++j2) {
-      uint4 af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) af[J2 & 1][i] = *(const uint4*)(fa[J2] + roff + IMM + i * 32 * BKB);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *(const uint4*)(fa[j2] + roff + IMM + i * 32 * BKB);
+        for (int j = 0; j < TN; ++j) bf[J2 & 1][j] = *(const uint4*)(fb[J2] + roff + IMM + j * 32 * BKB);
+      };
+      load(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      static_for<CPR / 2>([&](auto j2c) {
+        constexpr int J2 = decltype(j2c)::value;
+        if constexpr (J2 + 1 < CPR / 2) load(std::integral_constant<int, J2 + 1>{});
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *(const uint4*)(fb[j2] + roff + IMM + j * 32 * BKB);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[J2 & 1][i], bf[J2 & 1][j]);
+        // issue order: one ds_read of the next step behind each of this step's first MFMAs
+        if constexpr (J2 + 1 < CPR / 2) {
+          static_for<TM + TN>([&](auto) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          });
+          __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+      });
+    } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
+      for (int j2 = 0; j2 < CPR / 2; ++j2) {
+        uint4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const uint4*)(fa[j2] + roff + IMM + i * 32 * BKB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *(const uint4*)(fb[j2] + roff + IMM + j * 32 * BKB);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
+      }
     }
   };
   typedef std::integral_constant<int, 0> zero_c;

@@ -7,7 +7,12 @@ N, H, W, Cin, Cout, k, stride, pad = [int(v) for v in sys.argv[1:9]]
 iters = int(sys.argv[9]) if len(sys.argv) > 9 else 50
 res = int(sys.argv[10]) if len(sys.argv) > 10 else 0
 dt = torch.bfloat16
-x = torch.randn(N, H, W, Cin, device='cuda').to(dt)
+x = torch.randn(N, H, W, Cin, device='cuda')
+mode = os.environ.get('MCG_BENCH_DATA', 'randn')   # the rate depends on the operand bits: the kernel sits on the package power cap
+if mode == 'zeros': x.zero_()
+elif mode == 'relu': x.relu_()
+elif mode == 'small': x.mul_(1e-3)
+x = x.to(dt)
 w = (torch.randn(Cout, k, k, Cin, device='cuda') / (Cin * k * k) ** 0.5).to(dt)
 b = torch.randn(Cout, device='cuda')
 Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
@@ -21,4 +26,4 @@ for _ in range(iters):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / iters * 1e3
 fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
-print(f'conv N={N} {H}x{W} {Cin}->{Cout} k{k} s{stride}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TF/s  (MCG_TILE={os.environ.get("MCG_TILE", "auto")})')
+print(f'conv N={N} {H}x{W} {Cin}->{Cout} k{k} s{stride}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TF/s  (MCG_TILE={os.environ.get("MCG_TILE", "auto")}, data={mode})')
