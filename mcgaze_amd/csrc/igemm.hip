@@ -115,7 +115,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   // MCG_FORCE_NARROW=1 its 64-byte K slices, MCG_TILE=1 the 256x128 DMA tile.
   static const int use_v1 = env_int("MCG_IGEMM", 0), force_narrow = env_int("MCG_FORCE_NARROW", 0), wide16 = env_int("MCG_WIDE16", 1);
   const int big_tile = env_int("MCG_TILE", -1);
-  static const int t12_min = env_int("MCG_T12_MIN", 320), t9_min = env_int("MCG_T9_MIN", 300), t14_min = env_int("MCG_T14_MIN", 1000);  // read per call: tests and tools/tile_sweep.sh switch tiles inside one process
+  static const int t12_min = env_int("MCG_T12_MIN", 320), t9_min = env_int("MCG_T9_MIN", 300), t14_min = env_int("MCG_T14_MIN", 384);  // read per call: tests and tools/tile_sweep.sh switch tiles inside one process
   const bool dma = ES == 2 && !use_v1 && dma_eligible(p, ES);
   const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0 && (!p.x2 || (p.Cin2 * ES) % 128 == 0);
   MCG_CHECK_ARG((p.Cin * ES) % 64 == 0 && (!p.x2 || (p.Cin2 * ES) % 64 == 0), "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
@@ -130,7 +130,8 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   //   N <= 256 layers one launch at a time, but not once two frame ranges run concurrently (profiles/r01_i_tile16.md) -- not chosen
   //   21 / 22 = 256x256 8w (64x128 / 128x64 wave tiles, fragments double-buffered in registers), 128-byte K slices, 2st: 2-3 % behind 14
   //   at the same package power (profiles/r01_j_power.md) -- sweep options only
-  //   14 = 256x256 16w, 128-byte K slices, 2st: half the barriers of 12 per K; +3 % on the K >= 1000 layers (3x3s, layer3/4 conv1), MCG_T14_MIN
+  //   14 = 256x256 16w, 128-byte K slices, 2st: half the barriers of 12 per K; +3 % on the K >= 1000 layers (3x3s, layer3/4 conv1), neutral
+  //   below; taken wherever 12 would be and the channel count allows 128-byte slices (MCG_T14_MIN = smallest K, 0 = never)
   int tile = 8;
   if (dma && p.Cout > 64) {
     const long long blocks9 = (long long)((p.M + 255) / 256) * ((p.Cout + 127) / 128);
