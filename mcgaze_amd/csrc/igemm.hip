@@ -83,11 +83,11 @@ static void launch_cfg(hipStream_t s, const IgemmParams& p, int groups) {
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, BKB, WM, WN>), grid, dim3(256), 0, s, p);
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int ST, int MINW = 2, bool PF = false>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int ST, int MINW = 2>
 static void launch_dma(hipStream_t s, const IgemmParams& p, int groups) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
   dim3 grid(tiles, p.splitk, groups);
-  hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, BKB, WM, WN, ST, MINW, PF>), grid, dim3(64 * WM * WN), 0, s, p);
+  hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, BKB, WM, WN, ST, MINW>), grid, dim3(64 * WM * WN), 0, s, p);
 }
 
 // The DMA kernel addresses both operands through 2 GiB buffer descriptors with 32-bit offsets and keeps the
@@ -166,8 +166,6 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     else if (tile == 12) launch_dma<T, 256, 256, 64, 4, 4, 3, 4>(s, p, groups);
     else if (tile == 13) launch_dma<T, 256, 256, 64, 4, 4, 2, 4>(s, p, groups);
     else if (tile == 14 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 4, 2, 4>(s, p, groups);
-    else if (tile == 24) launch_dma<T, 256, 256, 64, 2, 2, 4, 1, true>(s, p, groups);
-    else if (tile == 25) launch_dma<T, 256, 256, 64, 4, 2, 4, 2, true>(s, p, groups);
     else if (tile == 21 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 2, 2, 2>(s, p, groups);
     else if (tile == 22 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 2, 4, 2, 2>(s, p, groups);
     else launch_dma<T, 128, 128, 64, 2, 2, 4>(s, p, groups);

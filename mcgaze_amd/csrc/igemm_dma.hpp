@@ -68,7 +68,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <typename T, int BM, int BN, int BKB, int WAVES_M, int WAVES_N, int STAGES, int MINW = 2, bool PF = false>
+template <typename T, int BM, int BN, int BKB, int WAVES_M, int WAVES_N, int STAGES, int MINW = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel(const IgemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
   constexpr int ES = (int)sizeof(T);
@@ -278,37 +278,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   // Big wave tiles (>= 8 MFMAs per K-step) run two waves per SIMD: too few to hide an LDS round trip per K-step behind the other
   // waves, so the fragments are double-buffered in registers -- step j+1's reads are issued before step j's MFMAs.
   constexpr bool SWP = TM * TN >= 8 && CPR / 2 >= 2;
-  // PF (needs SWP, STAGES >= 3, an even number of K-steps per tile): the barrier of iteration kt also guarantees tile kt+1 has landed
-  // (the vmcnt wait runs one tile ahead), so the first K-step's fragments of tile kt+1 are read BEFORE the barrier that ends tile kt
-  // and the MFMAs restart the moment it opens -- for one-wave-per-SIMD tiles, where nothing else covers that LDS round trip.
-  static_assert(!PF || (SWP && STAGES >= 3 && (CPR / 2) % 2 == 0), "cross-barrier fragment prefetch: see above");
-  constexpr int LAND = PF ? STAGES - 3 : STAGES - 2;   // DMA groups of this wave that may still be in flight at the barrier
-  uint4 af[SWP ? 2 : 1][TM], bf[SWP ? 2 : 1][TN];
-  auto load_frags = [&](auto j2c, auto imm_c, uint32_t roff) {   // K-step J2 of the tile in ring slot (IMM + roff) -> buffer J2 & 1
-    constexpr int J2 = decltype(j2c)::value, IMM = decltype(imm_c)::value, B = SWP ? (J2 & 1) : 0;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[B][i] = *(const uint4*)(fa[J2] + roff + IMM + i * 32 * BKB);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bf[B][j] = *(const uint4*)(fb[J2] + roff + IMM + j * 32 * BKB);
-  };
-  typedef std::integral_constant<int, 0> zero_c;
-  auto compute_tile = [&](auto imm_c, uint32_t roff, auto immn_c, uint32_t roffn) {
+  auto compute_tile = [&](auto imm_c, uint32_t roff) {
+    constexpr int IMM = decltype(imm_c)::value;
     if constexpr (SWP) {
-      if constexpr (!PF) {
-        load_frags(zero_c{}, imm_c, roff);
-        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-      }
+      uint4 af[2][TM], bf[2][TN];
+      auto load = [&](auto j2c) {
+        constexpr int J2 = decltype(j2c)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[J2 & 1][i] = *(const uint4*)(fa[J2] + roff + IMM + i * 32 * BKB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[J2 & 1][j] = *(const uint4*)(fb[J2] + roff + IMM + j * 32 * BKB);
+      };
+      load(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       static_for<CPR / 2>([&](auto j2c) {
         constexpr int J2 = decltype(j2c)::value;
-        constexpr bool more = J2 + 1 < CPR / 2;
-        if constexpr (more) load_frags(std::integral_constant<int, J2 + 1>{}, imm_c, roff);
-        else if constexpr (PF) load_frags(zero_c{}, immn_c, roffn);   // past the last tile this reads a stale slot, unused
+        if constexpr (J2 + 1 < CPR / 2) load(std::integral_constant<int, J2 + 1>{});
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[J2 & 1][i], bf[J2 & 1][j]);
         // issue order: one ds_read of the next step behind each of this step's first MFMAs
-        if constexpr (more || PF) {
+        if constexpr (J2 + 1 < CPR / 2) {
           static_for<TM + TN>([&](auto) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -319,56 +310,49 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
         }
       });
     } else {
-      constexpr int IMM = decltype(imm_c)::value;
 #pragma unroll
       for (int j2 = 0; j2 < CPR / 2; ++j2) {
-        uint4 a1[TM], b1[TN];
+        uint4 af[TM], bf[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a1[i] = *(const uint4*)(fa[j2] + roff + IMM + i * 32 * BKB);
+        for (int i = 0; i < TM; ++i) af[i] = *(const uint4*)(fa[j2] + roff + IMM + i * 32 * BKB);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b1[j] = *(const uint4*)(fb[j2] + roff + IMM + j * 32 * BKB);
+        for (int j = 0; j < TN; ++j) bf[j] = *(const uint4*)(fb[j2] + roff + IMM + j * 32 * BKB);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], a1[i], b1[j]);
+          for (int j = 0; j < TN; ++j) Mma<T>::run(acc[i][j], af[i], bf[j]);
       }
     }
   };
+  typedef std::integral_constant<int, 0> zero_c;
 
   // tile t lives in ring slot t % STAGES; the slot tile t-1 just released receives tile t + STAGES - 1
   const int n_pre = min(n_tiles, STAGES - 1);
   static_for<STAGES - 1>([&](auto s) { if (decltype(s)::value < n_pre) issue_tile(std::integral_constant<int, decltype(s)::value * STAGE>{}, 0u); });
   const int n_main = n_tiles - n_pre;  // tiles whose step still has a successor to issue
-  if constexpr (PF) {
-    if (n_pre == STAGES - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_PER_WAVE * (STAGES - 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // tile 0 landed
-    load_frags(zero_c{}, zero_c{}, 0u);
-  }
   int kt = 0;
   for (; kt + STAGES <= n_main; kt += STAGES)  // steady state, unrolled over the ring so slots are immediates
     static_for<STAGES>([&](auto s) {
       constexpr int S = decltype(s)::value;
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES_PER_WAVE * LAND) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES_PER_WAVE * (STAGES - 2)) : "memory");
       __builtin_amdgcn_s_barrier();
       issue_tile(std::integral_constant<int, ((S + STAGES - 1) % STAGES) * STAGE>{}, 0u);
-      compute_tile(std::integral_constant<int, S * STAGE>{}, 0u, std::integral_constant<int, ((S + 1) % STAGES) * STAGE>{}, 0u);
+      compute_tile(std::integral_constant<int, S * STAGE>{}, 0u);
     });
   // remainder (< STAGES issuing steps) and drain (n_pre steps, nothing left to issue): rolled, run-time slot
   uint32_t rs = 0, rn = (STAGES - 1) * STAGE;
 #pragma nounroll
   for (; kt < n_tiles; ++kt) {
     if (kt < n_main) {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES_PER_WAVE * LAND) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES_PER_WAVE * (STAGES - 2)) : "memory");
       __builtin_amdgcn_s_barrier();
       issue_tile(zero_c{}, rn);
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    const uint32_t rs_next = rs + STAGE == STAGES * STAGE ? 0 : rs + STAGE;
-    compute_tile(zero_c{}, rs, zero_c{}, rs_next);
-    rs = rs_next;
+    compute_tile(zero_c{}, rs);
+    rs = rs + STAGE == STAGES * STAGE ? 0 : rs + STAGE;
     rn = rn + STAGE == STAGES * STAGE ? 0 : rn + STAGE;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing prefetch pieces must land before LDS is reused

@@ -182,7 +182,7 @@ def test_every_dma_tile_is_bit_identical(eng, shape, monkeypatch):
     ho = (h + 2 * pad - k) // stride + 1
     r = torch.randn(n, ho, (w + 2 * pad - k) // stride + 1, cout, generator=g).to(torch.bfloat16).to('cuda:0')
     outs = {}
-    for tile in (9, 0, 1, 2, 3, 8, 10, 11, 12, 13, 14, 15, 16, 21, 22, 24, 25):
+    for tile in (9, 0, 1, 2, 3, 8, 10, 11, 12, 13, 14, 15, 16, 21, 22):
         monkeypatch.setenv('MCG_TILE', str(tile))
         outs[tile] = eng.conv2d(x, wt, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1).clone()
     torch.cuda.synchronize()
