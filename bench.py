@@ -238,10 +238,17 @@ def main():
         }
         if world == 1 and a.cpu_seconds > 0:
             line['cpu_baseline'] = cpu_baseline(a.cpu_seconds, T, a.size)
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     if dist is not None:
         dist.barrier(device_ids=[local])
         dist.destroy_process_group()
+    # The JSON line is the LAST thing on stdout: RCCL writes a "Librccl path" notice through C stdio, which is block-buffered on a
+    # pipe and would otherwise surface after Python's line at exit.
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':
