@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOPS_PER_CLIP_TRUNK = 97.01e9    # backbone + FPN only
+FLOPS_PER_CLIP_BACKBONE = 57.22e9  # R-50 alone, 8.174 GFLOP per frame
 FLOPS_PER_CLIP = 99.55e9          # 2*MAC over convs + linears + bmms, 7x3x224x224 clip
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
@@ -51,9 +52,9 @@ def parse():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--chunk-frames', type=int, default=0)
-    ap.add_argument('--workload', default='full', choices=['full', 'backbone_fpn'],
+    ap.add_argument('--workload', default='full', choices=['full', 'backbone_fpn', 'backbone'],
                     help="'full' = BASELINE.json configs[2] (the metric's configuration); 'backbone_fpn' = configs[1], the trunk alone "
-                         '(use --clips-per-gpu 32 for its 32 x 7 frames)')
+                         "(use --clips-per-gpu 32 for its 32 x 7 frames); 'backbone' = the same without the FPN")
     ap.add_argument('--pipeline', type=int, default=1, choices=[0, 1],
                     help='1: two-deep batch pipeline (decoder of step k overlaps trunk of step k+1 on a second stream; '
                          'every batch is fully processed inside the timed region), 0: one stream, strictly serial')
@@ -106,6 +107,8 @@ def main():
     from mcgaze_amd.engine import HipEngine
     from mcgaze_amd.dist import ResultGather
 
+    if a.workload == 'backbone':
+        os.environ['MCG_TRUNK_STOP'] = 'backbone'
     lib = L.load()
     B, T = a.clips_per_gpu, a.clip_length
     N = B * T
@@ -124,7 +127,7 @@ def main():
     gathered = [None, None]
 
     def step():
-        if a.workload == 'backbone_fpn':
+        if a.workload != 'full':
             eng.backbone_fpn(img, a.chunk_frames)
             return
         slot = state['k'] & 1
@@ -220,13 +223,13 @@ def main():
         elapsed = float(t.item())
     if rank == 0:
         total_clips = B * world * a.steps
-        flops_per_clip = FLOPS_PER_CLIP if a.workload == 'full' else FLOPS_PER_CLIP_TRUNK
+        flops_per_clip = {'full': FLOPS_PER_CLIP, 'backbone_fpn': FLOPS_PER_CLIP_TRUNK, 'backbone': FLOPS_PER_CLIP_BACKBONE}[a.workload]
         value = total_clips / elapsed
         line = {
             'metric': 'clips/sec (7x3x224x224)', 'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic (seeded N(0,1) clips, random-init weights, resident in HBM)',
-            'config': {'workload': ('full multiclue_gaze_r50 forward (R-50 + FPN + 4 decoder stages + gaze head), ' if a.workload == 'full' else 'R-50 backbone + FPN only (BASELINE.json configs[1]), ') +
+            'config': {'workload': {'full': 'full multiclue_gaze_r50 forward (R-50 + FPN + 4 decoder stages + gaze head), ', 'backbone_fpn': 'R-50 backbone + FPN only (BASELINE.json configs[1]), ', 'backbone': 'R-50 backbone only, C2..C5 (BASELINE.json configs[1]; MCG_TRUNK_STOP=backbone), '}[a.workload] +
                                    f'{B} clips/GPU x {T} frames x 3x{a.size}x{a.size}, {B * world} clips/step',
                        'clips_per_gpu': B, 'clip_length': T, 'global_clips': B * world, 'chunk_frames': a.chunk_frames,
                        'parallelism': f'dp{world} (clips sharded by rank, one fused all_gather of results per step)' if world > 1 else 'single GPU',

@@ -239,6 +239,10 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
       ci += has_ds ? 4 : 3;
     }
   }
+  {  // measurement switch (bench.py --workload backbone, BASELINE.json configs[1] "backbone-only"): stop after C5, pyramid not written
+    const char* stop = getenv("MCG_TRUNK_STOP");
+    if (stop && !strcmp(stop, "backbone")) return MCG_OK;
+  }
   // FPN (fpn.py:157-180): laterals top-down with the nearest-upsample add fused into the epilogue
   int hs[4], wsz[4];
   for (int i = 0; i < 4; ++i) { hs[i] = (H / 4) >> i; wsz[i] = (W / 4) >> i; }
