@@ -25,6 +25,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FLOPS_PER_CLIP_TRUNK = 97.01e9    # backbone + FPN only
 FLOPS_PER_CLIP_BACKBONE = 57.22e9  # R-50 alone, 8.174 GFLOP per frame
 FLOPS_PER_CLIP = 99.55e9          # 2*MAC over convs + linears + bmms, 7x3x224x224 clip
@@ -214,10 +215,15 @@ def main():
         t_ms, flops, n = by[dom]
         achieved = flops / (t_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if dom >= 4 else PEAK_F32_TFLOPS
-        traffic = None
+        traffic, step_bytes, covered = None, 0.0, 0
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tpath):
-            traffic = (json.load(open(tpath)).get(CFG_NAMES[dom]) or {}).get('hbm_bytes_per_launch')
+            tj = json.load(open(tpath))
+            traffic = (tj.get(CFG_NAMES[dom]) or {}).get('hbm_bytes_per_launch')
+            for c, v in by.items():   # HBM-side bytes of one step's contraction launches: per-symbol PMC average x launches
+                b = (tj.get(CFG_NAMES.get(c, '')) or {}).get('hbm_bytes_per_launch')
+                if b:
+                    step_bytes += b * v[2]; covered += v[2]
         roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                     'traffic': traffic, 'kernel': CFG_NAMES[dom], 'launches_per_step': n,
                     'avg_launch_ms': round(t_ms / n, 4), 'algorithmic_gflop_per_launch': round(flops / n / 1e9, 2),
@@ -225,6 +231,9 @@ def main():
                                                  for c, v in sorted(by.items())},
                     'sampled': "every contraction launch of the first timed step, HIP events on the launch stream; that step's trunk runs on one stream (MCG_TRUNK_STREAMS=1) so a launch's duration is its own -- the other steps run two frame ranges on concurrent streams",
                     'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_bench_traffic.sh); bytes per launch'}
+        if step_bytes:
+            roofline['hbm_step'] = {'bytes': int(step_bytes), 'contraction_launches_covered': covered, 'of': len(rec), 'peak_GBps': PEAK_HBM_GBPS,
+                                    'note': 'divide by ms_per_step for the whole-path HBM rate; stem, RoIAlign and the small decoder kernels are not in it'}
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -234,6 +243,9 @@ def main():
         total_clips = B * world * a.steps
         flops_per_clip = {'full': FLOPS_PER_CLIP, 'backbone_fpn': FLOPS_PER_CLIP_TRUNK, 'backbone': FLOPS_PER_CLIP_BACKBONE}[a.workload]
         value = total_clips / elapsed
+        if roofline and 'hbm_step' in roofline:
+            gbps = roofline['hbm_step']['bytes'] / (elapsed / a.steps) / 1e9
+            roofline['hbm_step'].update({'achieved_GBps': round(gbps, 1), 'frac': round(gbps / PEAK_HBM_GBPS, 4)})
         line = {
             'metric': 'clips/sec (7x3x224x224)', 'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
