@@ -177,9 +177,9 @@ def test_pipelined_runner_matches_serial_engine(engines):
             assert torch.equal(a[k], b[k]), (i, k)
 
 
-@pytest.mark.parametrize('B,T,H,W', [(1, 33, 64, 96), (3, 1, 96, 64), (1, 2, 448, 448)])
+@pytest.mark.parametrize('B,T,H,W', [(1, 33, 64, 96), (3, 1, 96, 64), (1, 2, 448, 448), (1, 101, 64, 64)])
 def test_fp32_engine_matches_oracle_on_unusual_shapes(engines, B, T, H, W):
-    """Shapes the reference supports but the goldens do not cover: a long clip (the demo feeds up to 101 frames,
+    """Shapes the reference supports but the goldens do not cover: long clips (33 frames; 101, the longest the demo feeds:
     SURVEY.md section 8(b)), single-frame clips, and the L2CS input size 448x448 -- fp32 engine vs the oracle at north_star's
     tolerance (the oracle itself is pinned to the reference by tests/test_oracle.py)."""
     sd = synth.make_state_dict(0)
