@@ -264,15 +264,21 @@ def main():
             line['cpu_baseline'] = cpu_baseline(a.cpu_seconds, T, a.size)
     else:
         line = None
-    if dist is not None:
-        dist.barrier(device_ids=[local])
-        dist.destroy_process_group()
-    # The JSON line is the LAST thing on stdout: RCCL writes a "Librccl path" notice through C stdio, which is block-buffered on a
-    # pipe and would otherwise surface after Python's line at exit.
+    # The JSON line is the LAST thing on stdout, across all ranks: RCCL writes a banner ("RCCL version ... Librccl path") through C
+    # stdio, which is block-buffered on a pipe and would otherwise surface at process exit, after Python's line.  Every rank pushes
+    # what it has buffered out now; ranks other than 0 then point their stdout at stderr; rank 0 prints after the barrier and does
+    # the same before the process group is torn down.
     sys.stdout.flush()
     C.CDLL(None).fflush(None)
+    if rank != 0:
+        os.dup2(2, 1)
+    if dist is not None:
+        dist.barrier(device_ids=[local])
     if line is not None:
         print(json.dumps(line), flush=True)
+    os.dup2(2, 1)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
