@@ -1,0 +1,27 @@
+#!/bin/bash
+# GPU: matrix-pipe utilisation per kernel symbol over single-stream steps of bench.py: SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32
+# shader engines x 1024 SIMDs), summed over every launch of the symbol.  Prints a markdown table (-> profiles/).
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_mfma; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+MCG_TRUNK_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY -d $OUT/sq -o sq --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel-events none --pipeline 0 > $OUT/sq.log 2>&1
+echo "pass rc=$?"
+cd $R
+python - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
+for f in glob.glob(f'{out}/sq/**/*counter_collection.csv', recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row['Kernel_Name'].split('(')[0].replace('void ', '')
+        agg[k][row['Counter_Name']] += float(row['Counter_Value'])
+        if row['Counter_Name'] == 'SQ_BUSY_CYCLES': calls[k] += 1
+tot_busy = sum(d['SQ_BUSY_CYCLES'] for d in agg.values())
+tot_mfma = sum(d['SQ_VALU_MFMA_BUSY_CYCLES'] for d in agg.values())
+print('| kernel | launches | share of GPU cycles | matrix pipe busy | waves waiting (WAIT_ANY / WAVE_CYCLES) |')
+print('|---|---|---|---|---|')
+for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['SQ_BUSY_CYCLES']):
+    if d['SQ_BUSY_CYCLES'] / tot_busy < 0.004: continue
+    util = d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['SQ_BUSY_CYCLES'] / 32 * 1024)
+    print(f"| `{k[:70]}` | {calls[k]} | {d['SQ_BUSY_CYCLES'] / tot_busy * 100:.1f} % | {util * 100:.1f} % | {d['SQ_WAIT_ANY'] / max(d['SQ_WAVE_CYCLES'], 1) * 100:.0f} % |")
+print(f'| all kernels | {sum(calls.values())} | 100 % | {tot_mfma / (tot_busy / 32 * 1024) * 100:.1f} % | |')
+PY
