@@ -40,7 +40,9 @@ CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,
              19: 'igemm_dma_kernel<bf16,256,256,64,4,2,3>', 24: 'igemm_dma_kernel<bf16,128,128,64,2,2,2>',
              25: 'igemm_dma_kernel<bf16,256,128,64,4,2,2>', 26: 'igemm_dma_kernel<bf16,128,128,64,2,2,3>',
              27: 'igemm_dma_kernel<bf16,128,128,64,4,2,2>', 28: 'igemm_dma_kernel<bf16,256,256,64,4,4,3>',
-             29: 'igemm_dma_kernel<bf16,256,256,64,4,4,2>', 30: 'igemm_dma_kernel<bf16,256,256,128,4,4,2>', 31: 'igemm_dma_kernel<bf16,128,128,64,4,2,3>', 32: 'igemm_dma_kernel<bf16,256,128,64,4,2,3> (<=128 VGPRs)', 40: 'conv3x3_c64_kernel'}
+             29: 'igemm_dma_kernel<bf16,256,256,64,4,4,2>', 30: 'igemm_dma_kernel<bf16,256,256,128,4,4,2>', 31: 'igemm_dma_kernel<bf16,128,128,64,4,2,3>', 32: 'igemm_dma_kernel<bf16,256,128,64,4,2,3> (<=128 VGPRs)', 40: 'conv3x3_c64_kernel',
+             # bf16x3 contraction (f32 activations, split-packed weights, 3 bf16 MFMAs per product)
+             50: 'igemm_dma_kernel<float,256,256,128,4,2,2,2,x3>', 51: 'igemm_dma_kernel<float,128,128,128,2,2,2,2,x3>', 52: 'igemm_dma_kernel<float,256,64,128,4,1,2,2,x3>'}
 
 
 def parse():
@@ -51,7 +53,7 @@ def parse():
     ap.add_argument('--clips-per-gpu', type=int, default=64)
     ap.add_argument('--clip-length', type=int, default=7)
     ap.add_argument('--size', type=int, default=224)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
     ap.add_argument('--chunk-frames', type=int, default=0)
     ap.add_argument('--workload', default='full', choices=['full', 'backbone_fpn', 'backbone'],
                     help="'full' = BASELINE.json configs[2] (the metric's configuration); 'backbone_fpn' = configs[1], the trunk alone "
@@ -214,7 +216,7 @@ def main():
         dom = max(by, key=lambda c: by[c][0])
         t_ms, flops, n = by[dom]
         achieved = flops / (t_ms * 1e-3) / 1e12
-        peak = PEAK_BF16_TFLOPS if dom >= 4 else PEAK_F32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if dom >= 4 else PEAK_F32_TFLOPS   # bf16x3 (50..52) is priced against the bf16 peak too: it issues 3 bf16 MFMAs per algorithmic product
         traffic, step_bytes, covered = None, 0.0, 0
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tpath):

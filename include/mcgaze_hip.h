@@ -14,8 +14,9 @@
  *   - no allocation on the hot path: scratch comes from a caller-provided workspace
  *   - return value: MCG_OK or an MCG_ERR_* code; mcg_last_error() gives the message
  *   - activations are NHWC ("channels last"): [frame][y][x][channel]; dtype is MCG_F32
- *     (parity mode, f32 MFMA, exact f32 accumulate chains) or MCG_BF16 (throughput mode,
- *     bf16 MFMA, f32 accumulate).  Bias / LayerNorm parameters / boxes are always f32.
+ *     (reference mode, f32 MFMA, exact f32 accumulate chains), MCG_BF16X3 (parity-grade fast
+ *     mode: f32 storage, split-bf16 x 3 MFMA contraction) or MCG_BF16 (throughput mode,
+ *     bf16 storage and MFMA, f32 accumulate).  Bias / LayerNorm parameters / boxes are always f32.
  *   - conv / linear weights are "OHWI": [Cout][KH][KW][Cin] (K contiguous), BN folded in.
  */
 #ifndef MCGAZE_HIP_H
@@ -28,10 +29,15 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 2
+#define MCG_ABI_VERSION 3
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
-typedef enum { MCG_F32 = 0, MCG_BF16 = 1 } mcg_dtype;
+/* MCG_BF16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
+ * f32 storage); only the contraction differs: every conv / linear weight matrix is handed over SPLIT-PACKED -- per 8 consecutive
+ * K elements a 16-byte chunk of bf16 high parts followed by a 16-byte chunk of bf16 low parts (w = hi + lo, lo = bf16(w - hi);
+ * 4 bytes per element like f32) -- the f32 activations are split the same way in registers, and each product runs as three bf16
+ * MFMAs (hi.hi + hi.lo + lo.hi) with f32 accumulation.  3-5e-5 rad on (yaw, pitch) against the reference (north_star: 1e-3). */
+typedef enum { MCG_F32 = 0, MCG_BF16 = 1, MCG_BF16X3 = 2 } mcg_dtype;
 typedef void* mcg_stream; /* hipStream_t */
 
 int mcg_abi_version(void);

@@ -83,11 +83,11 @@ static void launch_cfg(hipStream_t s, const IgemmParams& p, int groups) {
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, BKB, WM, WN>), grid, dim3(256), 0, s, p);
 }
 
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int ST, int MINW = 2>
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int ST, int MINW = 2, int X3 = 0>
 static void launch_dma(hipStream_t s, const IgemmParams& p, int groups) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
   dim3 grid(tiles, p.splitk, groups);
-  hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, BKB, WM, WN, ST, MINW>), grid, dim3(64 * WM * WN), 0, s, p);
+  hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, BKB, WM, WN, ST, MINW, X3>), grid, dim3(64 * WM * WN), 0, s, p);
 }
 
 // The DMA kernel addresses both operands through 2 GiB buffer descriptors with 32-bit offsets and keeps the
@@ -181,8 +181,37 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
   return MCG_OK;
 }
 
+// MCG_BF16X3: f32 activations x split-packed bf16 weights, three bf16 MFMAs per product (igemm_dma.hpp, X3 mode).
+//   50 = 256x256 8 waves (64x128 wave tiles: the A split is shared by four column tiles), 2 stages, 128 KiB -- deep, wide layers
+//   51 = 128x128 4 waves, 2 stages, 64 KiB (two workgroups per CU) -- Cout < 256, few rows (7x7 maps, decoder linears)
+//   52 = 256x64 4 waves -- Cout <= 64
+static int launch_x3(hipStream_t s, const IgemmParams& p, int groups) {
+  MCG_CHECK_ARG(p.Cin % 32 == 0 && (!p.x2 || p.Cin2 % 32 == 0), "igemm (bf16x3): Cin=%d must be a multiple of 32", p.Cin);
+  MCG_CHECK_ARG(p.Cout % 4 == 0, "igemm (bf16x3): Cout=%d must be a multiple of 4", p.Cout);
+  if (!dma_eligible(p, 4)) {
+    mcg_set_error("igemm (bf16x3): operand beyond the 2 GiB descriptor window or more than 32 taps (M=%d Cin=%d %dx%d)", p.M, p.Cin, p.KH, p.KW);
+    return MCG_ERR_UNSUPPORTED;
+  }
+  const long long t256 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
+  const int tile = p.Cout <= 64 ? 52 : (p.Cout % 256 == 0 && t256 >= 200 ? 50 : 51);
+  ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
+  if (rec) {
+    rec->cfg = tile;
+    rec->shape[0] = p.M; rec->shape[1] = p.Cout * groups; rec->shape[2] = p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
+    rec->flops = 2.0 * p.M * p.Cout * (p.algo_k > 0 ? (double)p.algo_k : (double)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0)) * groups;
+    (void)hipEventRecord(rec->a, s);
+  }
+  if (tile == 50) launch_dma<float, 256, 256, 128, 4, 2, 2, 2, 1>(s, p, groups);
+  else if (tile == 51) launch_dma<float, 128, 128, 128, 2, 2, 2, 2, 1>(s, p, groups);
+  else launch_dma<float, 256, 64, 128, 4, 1, 2, 2, 1>(s, p, groups);
+  if (rec) (void)hipEventRecord(rec->b, s);
+  MCG_CHECK_LAUNCH("igemm (bf16x3) launch");
+  return MCG_OK;
+}
+
 int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p, int groups) {
   MCG_CHECK_ARG(p.M > 0 && p.Cout > 0 && groups > 0, "igemm: empty problem (M=%d Cout=%d groups=%d)", p.M, p.Cout, groups);
+  if (dt == MCG_BF16X3) return launch_x3(s, p, groups);
   return dt == MCG_BF16 ? launch_typed<bf16_t>(s, p, groups) : launch_typed<float>(s, p, groups);
 }
 
@@ -210,7 +239,7 @@ int launch_linear_splitk(hipStream_t s, mcg_dtype dt, const void* x, long long l
   IgemmParams p = linear_params(x, lda, w, M, K, Cout);
   const int es = dt == MCG_BF16 ? 2 : 4;
   const bool dma = dt == MCG_BF16 && !env_int("MCG_IGEMM", 0);
-  const int bk = (dma || env_int("MCG_FORCE_NARROW", 0) ? 64 : (((long long)K * es) % 128 == 0 ? 128 : 64)) / es;
+  const int bk = dt == MCG_BF16X3 ? 32 : (dma || env_int("MCG_FORCE_NARROW", 0) ? 64 : (((long long)K * es) % 128 == 0 ? 128 : 64)) / es;
   const int KT = K / bk;
   int slices = want_slices < 1 ? 1 : (want_slices > KT ? KT : want_slices);
   const int per = (KT + slices - 1) / slices;

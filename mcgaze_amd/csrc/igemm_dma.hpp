@@ -68,8 +68,30 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <typename T, int BM, int BN, int BKB, int WAVES_M, int WAVES_N, int STAGES, int MINW = 2>
+// Eight f32 values (two 16-byte chunks) -> bf16 high parts and bf16 low parts: hi = RNE(x), lo = RNE(x - float(hi)); the
+// subtraction is exact (Sterbenz), so hi + lo = x to 2^-17 relative.
+__device__ __forceinline__ void split_f32x8(const uint4& c0, const uint4& c1, bf16x8& hi, bf16x8& lo) {
+  const uint32_t x[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = __uint_as_float(x[2 * q]), b = __uint_as_float(x[2 * q + 1]);
+    h[q] = pack2bf(a, b);
+    l[q] = pack2bf(a - __uint_as_float(h[q] << 16), b - __uint_as_float(h[q] & 0xffff0000u));
+  }
+  hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+  lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
+// X3 != 0 (T = float): the "bf16x3" contraction of the MCG_BF16X3 engine.  Activations stay f32 in HBM and LDS; the weight
+// operand is the split-packed form (packing.py::split_pack: per 8 consecutive K elements a 16-byte chunk of bf16 HIGH parts,
+// then a 16-byte chunk of bf16 LOW parts, w = hi + lo to 2^-17 -- 4 bytes per element, so the DMA geometry is that of an f32
+// matrix).  An A fragment is split in registers the same way (hi = RNE_bf16(x), lo = RNE_bf16(x - hi), the difference is exact)
+// and each 32x32x16 product is three v_mfma_f32_32x32x16_bf16: lo.hi + hi.lo + hi.hi, f32 accumulate (the dropped lo.lo term is
+// 2^-18 relative).  Measured end to end: 3-5e-5 rad on (yaw, pitch) against the f32 oracle, at bf16 matrix-pipe rate / 3.
+template <typename T, int BM, int BN, int BKB, int WAVES_M, int WAVES_N, int STAGES, int MINW = 2, int X3 = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel(const IgemmParams p) {
+  static_assert(!X3 || (sizeof(T) == 4 && BKB == 128), "bf16x3 mode: f32 storage, 128-byte K slices (32 channels)");
   constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
   constexpr int ES = (int)sizeof(T);
   constexpr int EPC = 16 / ES;
@@ -88,7 +110,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   // epilogue passes: as many wave-rows (WTM output rows each) per pass as fit the ring's footprint
   constexpr int WR_FIT = LDS_BYTES / (WTM * BN * 4);
   // ... rounded down to a divisor of WAVES_M: a last pass with fewer wave-rows than the others would store stale staging rows
-  constexpr int WR_PER_PASS = WR_FIT >= WAVES_M ? WAVES_M : (WR_FIT >= 4 && WAVES_M % 4 == 0 ? 4 : (WR_FIT >= 2 && WAVES_M % 2 == 0 ? 2 : 1));
+  constexpr int WR_WANT = WR_FIT >= WAVES_M ? WAVES_M : (WR_FIT >= 4 && WAVES_M % 4 == 0 ? 4 : (WR_FIT >= 2 && WAVES_M % 2 == 0 ? 2 : 1));
+  // ... and small enough that the double-buffered residual rows stay within 2 x 8 chunks per thread (f32 tiles are wide in chunks)
+  constexpr int WR_CAP = (8 * NT) / (WTM * (BN / EPC)) >= 1 ? (8 * NT) / (WTM * (BN / EPC)) : 1;
+  constexpr int WR_PER_PASS = !X3 ? WR_WANT : (WR_WANT <= WR_CAP ? WR_WANT : (WR_CAP >= 2 && WAVES_M % 2 == 0 ? 2 : 1));
   constexpr int PASSES = (WAVES_M + WR_PER_PASS - 1) / WR_PER_PASS;
   constexpr int PASS_ROWS = WR_PER_PASS * WTM;
   constexpr int CPRO = BN / EPC;                         // output chunks per row
@@ -271,7 +296,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   const char* fb[CPR / 2];
 #pragma unroll
   for (int j2 = 0; j2 < CPR / 2; ++j2) {
-    const int cb = ((2 * j2 + (lane >> 5)) ^ fkey) << 4;
+    // plain: K-chunk 2 j2 + half.  bf16x3: the lane's 8 channels of MFMA step j = j2 / 2 are chunks 4 j + 2 half + (j2 & 1): for A
+    // the first / last four f32 values, for W the bf16 high parts / low parts of the same 8 channels
+    const int chunk = X3 ? 4 * (j2 >> 1) + 2 * (lane >> 5) + (j2 & 1) : 2 * j2 + (lane >> 5);
+    const int cb = (chunk ^ fkey) << 4;
     fa[j2] = smem + (wm * WTM + (lane & 31)) * BKB + cb;
     fb[j2] = smem + A_BYTES + (wn * WTN + (lane & 31)) * BKB + cb;
   }
@@ -280,7 +308,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   constexpr bool SWP = TM * TN >= 8 && CPR / 2 >= 2;
   auto compute_tile = [&](auto imm_c, uint32_t roff) {
     constexpr int IMM = decltype(imm_c)::value;
-    if constexpr (SWP) {
+    if constexpr (X3 != 0) {
+      static_for<CPR / 4>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          split_f32x8(*(const uint4*)(fa[2 * J] + roff + IMM + i * 32 * BKB), *(const uint4*)(fa[2 * J + 1] + roff + IMM + i * 32 * BKB), ah[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(fb[2 * J] + roff + IMM + j * 32 * BKB));
+          bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(fb[2 * J + 1] + roff + IMM + j * 32 * BKB));
+        }
+        // small terms first; consecutive MFMAs never share an accumulator
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      });
+    } else if constexpr (SWP) {
       uint4 af[2][TM], bf[2][TN];
       auto load = [&](auto j2c) {
         constexpr int J2 = decltype(j2c)::value;

@@ -12,7 +12,10 @@ import torch
 from . import lib as L
 from .packing import PackedWeights
 
-_TORCH_DT = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32}
+# precision -> (storage dtype of activations, mcg_dtype code).  'bf16x3': f32 storage, split-bf16 x 3 MFMA contraction (parity-grade
+# fast mode, include/mcgaze_hip.h MCG_BF16X3)
+_TORCH_DT = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32, 'bf16x3': torch.float32}
+_CODE = {'bf16': L.MCG_BF16, 'fp32': L.MCG_F32, 'f32': L.MCG_F32, 'bf16x3': L.MCG_BF16X3}
 
 
 def _code(dtype):
@@ -57,12 +60,17 @@ def to_nchw(x_nhwc):
     return out
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual_mode=L.RES_NONE, x2=None, stride2=1):
-    """x NHWC, w OHWI (same dtype), bias f32 -> NHWC.  mcg_conv2d.  With x2: w = [Cout,1,1,Cin+Cin2], x2 sampled at stride2."""
+def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual_mode=L.RES_NONE, x2=None, stride2=1, split=False):
+    """x NHWC, w OHWI (same dtype), bias f32 -> NHWC.  mcg_conv2d.  With x2: w = [Cout,1,1,Cin+Cin2], x2 sampled at stride2.
+    split=True: the MCG_BF16X3 contraction -- x / residual f32, w given as f32 OHWI and split-packed here (packing.split_pack)."""
     _require_gpu()
     lib = L.load()
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
+    if split:
+        from .packing import split_pack
+        assert x.dtype == torch.float32 and w.dtype == torch.float32
+        w = split_pack(w.reshape(Cout, -1))
     Cin2 = x2.shape[3] if x2 is not None else 0
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     y = torch.empty(N, Ho, Wo, Cout, dtype=x.dtype, device=x.device)
@@ -72,7 +80,7 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual
                    residual.shape[1] if residual is not None else 0, residual.shape[2] if residual is not None else 0,
                    x2.data_ptr() if x2 is not None else None, Cin2, stride2, x2.shape[1] if x2 is not None else 0,
                    x2.shape[2] if x2 is not None else 0)
-    L.check(lib.mcg_conv2d(_stream(), _code(x.dtype), C.byref(d)), 'mcg_conv2d')
+    L.check(lib.mcg_conv2d(_stream(), L.MCG_BF16X3 if split else _code(x.dtype), C.byref(d)), 'mcg_conv2d')
     return y
 
 
@@ -109,13 +117,13 @@ def _table(d, keys):
     return (C.c_void_p * len(keys))(*[d[k].data_ptr() for k in keys])
 
 
-def stage_forward(stage_w, roi_feat, obj, boxes, clip_length, stds=(0.5, 0.5, 1.0, 1.0)):
+def stage_forward(stage_w, roi_feat, obj, boxes, clip_length, stds=(0.5, 0.5, 1.0, 1.0), split=False):
     """One decoder stage.  roi_feat [R,49,256], obj [N,3,256], boxes [N,3,4] f32
     -> (obj' [N,3,256], boxes' [N,3,4], cls logits [N,3]).  mcg_stage_forward."""
     _require_gpu()
     lib = L.load()
     N = obj.shape[0]
-    dt = _code(obj.dtype)
+    dt = L.MCG_BF16X3 if split else _code(obj.dtype)   # split: stage_w from PackedWeights(split=True), f32 activations
     ws = _ws(lib.mcg_stage_workspace_bytes(dt, N), obj.device)
     obj_out = torch.empty_like(obj)
     boxes_out = torch.empty(N, 3, 4, dtype=torch.float32, device=obj.device)
@@ -127,12 +135,12 @@ def stage_forward(stage_w, roi_feat, obj, boxes, clip_length, stds=(0.5, 0.5, 1.
     return obj_out, boxes_out, cls
 
 
-def gaze_head(gaze_w, obj):
+def gaze_head(gaze_w, obj, split=False):
     """obj [N,3,256] -> [4,N,3] f32 unit vectors (fused, face, eyes, head).  mcg_gaze_head."""
     _require_gpu()
     lib = L.load()
     N = obj.shape[0]
-    dt = _code(obj.dtype)
+    dt = L.MCG_BF16X3 if split else _code(obj.dtype)
     ws = _ws(lib.mcg_gaze_head_workspace_bytes(dt, N), obj.device)
     out = torch.empty(4, N, 3, dtype=torch.float32, device=obj.device)
     L.check(lib.mcg_gaze_head(_stream(), dt, _table(gaze_w, L.GAZE_KEYS), _ptr(obj.contiguous()), N, _ptr(out), _ptr(ws), ws.numel()), 'mcg_gaze_head')
@@ -148,9 +156,10 @@ class HipEngine:
         self.lib = L.load()
         self.device = torch.device(device)
         self.dtype = _TORCH_DT[precision]
+        self.code = _CODE[precision]
         self.precision = precision
         self.weights = PackedWeights(state_dict, depth=depth, num_stages=num_stages, dtype=self.dtype, device=self.device,
-                                     fuse_downsample=fuse_downsample)
+                                     fuse_downsample=fuse_downsample, split=self.code == L.MCG_BF16X3)
         w = self.weights
         mk = lambda c: L.ConvWeights(c['w'].data_ptr(), c['bias'].data_ptr(), c['cin'], c['cout'], c['k'], c['stride'], c['pad'])
         self._convs = (L.ConvWeights * len(w.convs))(*[mk(c) for c in w.convs])
@@ -172,7 +181,7 @@ class HipEngine:
         mw.gaze_weights = C.cast(self._gaze_tab, C.POINTER(C.c_void_p))
         mw.bbox_stds = (C.c_float * 4)(*bbox_stds)
         self._handle = C.c_void_p()
-        L.check(self.lib.mcg_engine_create(C.byref(self._handle), C.byref(mw), _code(self.dtype)), 'mcg_engine_create')
+        L.check(self.lib.mcg_engine_create(C.byref(self._handle), C.byref(mw), self.code), 'mcg_engine_create')
         self._ws = None
         self._ws_key = None
 

@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MCGAZE_LIB') or os.path.join(_HERE, 'libmcgaze_hip.so')   # MCGAZE_LIB: A/B a second build on one box
 
 MCG_OK = 0
-MCG_F32, MCG_BF16 = 0, 1
+MCG_F32, MCG_BF16, MCG_BF16X3 = 0, 1, 2
+ABI_VERSION = 3
 RES_NONE, RES_ADD, RES_UPSAMPLE_ADD = 0, 1, 2
 
 # enum order of include/mcgaze_hip.h
@@ -107,8 +108,8 @@ def load():
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('mcg_abi_version',):
             fn.restype = i
-    if lib.mcg_abi_version() != 2:
-        raise McgError(f'ABI mismatch: library reports {lib.mcg_abi_version()}, binding expects 2')
+    if lib.mcg_abi_version() != ABI_VERSION:
+        raise McgError(f'ABI mismatch: library reports {lib.mcg_abi_version()}, binding expects {ABI_VERSION}')
     _lib = lib
     return lib
 

@@ -59,6 +59,20 @@ def frag_major(w):
     return v.contiguous().reshape(*lead, 256, 256)
 
 
+def split_pack(w):
+    """f32 [..., K] -> bf16 [..., 2K], the weight operand of the MCG_BF16X3 contraction (include/mcgaze_hip.h): per 8 consecutive
+    K elements a 16-byte chunk of bf16 high parts, then a 16-byte chunk of bf16 low parts; hi = bf16(w), lo = bf16(w - hi)
+    (round to nearest even both times), so hi + lo = w to 2^-17 relative.  4 bytes per element, like the f32 matrix it replaces."""
+    w = w.float()
+    K = w.shape[-1]
+    assert K % 8 == 0, f'split_pack: K={K} must be a multiple of 8'
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    lead = w.shape[:-1]
+    v = torch.stack([hi.reshape(*lead, K // 8, 8), lo.reshape(*lead, K // 8, 8)], dim=-2)   # [..., K/8, 2, 8]
+    return v.reshape(*lead, 2 * K).contiguous()
+
+
 def dyn_permutation(d=256, feat=64):
     """Row permutation of dynamic_layer: new row n*d+k <- old row k*feat+n (param_in^T, [feat][d]);
     new row d*feat + n*feat+k <- old row d*feat + k*d+n (param_out^T, [d][feat]); transformer.py:1134-1137."""
@@ -72,18 +86,23 @@ def dyn_permutation(d=256, feat=64):
 class PackedWeights:
     """Device-resident packed weights + the geometry tables the engine needs."""
 
-    def __init__(self, state_dict, depth=50, num_stages=4, dtype=torch.bfloat16, device='cuda:0', fuse_downsample=True):
+    def __init__(self, state_dict, depth=50, num_stages=4, dtype=torch.bfloat16, device='cuda:0', fuse_downsample=True, split=False):
+        """``dtype``: storage type of activations (and of the matrices for MCG_F32 / MCG_BF16).  ``split=True`` (MCG_BF16X3, dtype
+        must be float32): every conv / linear matrix is split-packed bf16 (``split_pack``) over its flattened K = (kh, kw, cin)."""
         sd = normalize_state_dict(state_dict)
-        self.dtype, self.device, self.depth, self.num_stages = dtype, torch.device(device), depth, num_stages
+        self.dtype, self.device, self.depth, self.num_stages, self.split = dtype, torch.device(device), depth, num_stages, split
+        assert not split or dtype == torch.float32
         self.blocks = ARCH[depth]
         self._keep = []
-        mat = lambda t: self._dev(t.to(dtype))
+        # matrices: K is the trailing axis after flattening (kh, kw, cin) -- conv weights arrive here as OHWI
+        mat = (lambda t: self._dev(split_pack(t))) if split else (lambda t: self._dev(t.to(dtype)))               # [..., out, in]
+        cmat = (lambda t: self._dev(split_pack(t.reshape(t.shape[0], -1)))) if split else mat                      # OHWI conv weight
         vec = lambda t: self._dev(t.float())
 
         w, b = fold_bn(sd, 'backbone.conv1.weight', 'backbone.bn1')
         stem = torch.zeros(64, 7, 8, 4)
         stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
-        self.stem = dict(w=mat(stem), bias=vec(b), cin=32, cout=64, k=7, stride=2, pad=3)
+        self.stem = dict(w=cmat(stem), bias=vec(b), cin=32, cout=64, k=7, stride=2, pad=3)
         self.convs = []
         self.c3_ds = []  # per layer: first block's conv3 + downsample as one K-concatenated 1x1 conv
         for li, nb in enumerate(self.blocks):
@@ -92,22 +111,22 @@ class PackedWeights:
                 stride = 2 if (bi == 0 and li > 0) else 1
                 for conv, bn, k, s, pad in (('conv1', 'bn1', 1, 1, 0), ('conv2', 'bn2', 3, stride, 1), ('conv3', 'bn3', 1, 1, 0)):
                     w, b = fold_bn(sd, f'{p}.{conv}.weight', f'{p}.{bn}')
-                    self.convs.append(dict(w=mat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=k, stride=s, pad=pad))
+                    self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=k, stride=s, pad=pad))
                 if f'{p}.downsample.0.weight' in sd:
                     w3, b3 = w, b  # conv3 of this block (last of the loop above)
                     w, b = fold_bn(sd, f'{p}.downsample.0.weight', f'{p}.downsample.1')
-                    self.convs.append(dict(w=mat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=1, stride=stride, pad=0))
+                    self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=1, stride=stride, pad=0))
                     if fuse_downsample:
                         wcat = torch.cat([ohwi(w3), ohwi(w)], dim=3)  # [Cout,1,1,planes + inplanes]
-                        self.c3_ds.append(dict(w=mat(wcat), bias=vec(b3 + b), cin=wcat.shape[3], cout=wcat.shape[0], k=1, stride=1, pad=0))
+                        self.c3_ds.append(dict(w=cmat(wcat), bias=vec(b3 + b), cin=wcat.shape[3], cout=wcat.shape[0], k=1, stride=1, pad=0))
         self.lateral, self.fpn_out = [], []
         for i in range(4):
             w = sd[f'neck.lateral_convs.{i}.conv.weight']
-            self.lateral.append(dict(w=mat(ohwi(w)), bias=vec(sd[f'neck.lateral_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=1, stride=1, pad=0))
+            self.lateral.append(dict(w=cmat(ohwi(w)), bias=vec(sd[f'neck.lateral_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=1, stride=1, pad=0))
             w = sd[f'neck.fpn_convs.{i}.conv.weight']
-            self.fpn_out.append(dict(w=mat(ohwi(w)), bias=vec(sd[f'neck.fpn_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=3, stride=1, pad=1))
+            self.fpn_out.append(dict(w=cmat(ohwi(w)), bias=vec(sd[f'neck.fpn_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=3, stride=1, pad=1))
         self.init_boxes = vec(sd['rpn_head.init_proposal_bboxes.weight'])
-        self.init_feats = mat(sd['rpn_head.init_proposal_features.weight'])
+        self.init_feats = self._dev(sd['rpn_head.init_proposal_features.weight'].to(dtype))   # read by a non-GEMM kernel: storage dtype
         perm = dyn_permutation()
         self.stages = []
         for s in range(num_stages):
@@ -134,8 +153,8 @@ class PackedWeights:
                 HEAD_CLS_B=vec(torch.cat([sd[p + f'.{c}_fc_cls.bias'] for c in CLUES])),
                 HEAD_REG_W=vec(torch.stack([sd[p + f'.{c}_fc_reg.weight'] for c in CLUES])),
                 HEAD_REG_B=vec(torch.stack([sd[p + f'.{c}_fc_reg.bias'] for c in CLUES])))
-            for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W'):   # fragment-major copies for the fused chain kernel (chain.hpp)
-                st[k + 'F'] = frag_major(st[k])
+            for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W'):   # fragment-major copies for the fused chain kernel (chain.hpp, bf16 engine only)
+                st[k + 'F'] = frag_major(st[k]) if dtype == torch.bfloat16 else st[k]
             assert st['HEAD_CLS_W'].shape == (3, 256), 'use_sigmoid=True heads expected (gaze_stqi_head.py:72-75)'
             self.stages.append(st)
         # only the LAST stage's gaze head runs at inference (multiclue_gaze_roi_head.py:367,378)

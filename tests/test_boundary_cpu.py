@@ -117,7 +117,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.mcg_abi_version() == 2
+    assert lib.mcg_abi_version() == L.ABI_VERSION == int(re.search(r"#define MCG_ABI_VERSION (\d+)", hdr).group(1))
     # the binding's weight-table keys are the header's enums, in order
     sw = re.findall(r'MCG_SW_([A-Z0-9_]+)', hdr[hdr.index('MCG_SW_IN_PROJ_W = 0'):hdr.index('MCG_SW_COUNT')])
     gw = re.findall(r'MCG_GW_([A-Z0-9_]+)', hdr[hdr.index('MCG_GW_FC_W = 0'):hdr.index('MCG_GW_COUNT')])
@@ -174,3 +174,18 @@ def test_checkpoint_ingestion_envelope_and_key_rewrite(tmp_path):
     torch.save([1, 2, 3], bare)
     with pytest.raises(RuntimeError, match='No state_dict'):
         load_checkpoint(m2, bare)
+
+
+def test_split_pack_layout_and_accuracy():
+    """packing.split_pack (the MCG_BF16X3 weight operand): per 8 K elements 8 bf16 high parts then 8 bf16 low parts; hi + lo
+    reproduces the f32 value to 2^-17 relative."""
+    from mcgaze_amd.packing import split_pack
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(6, 64, generator=g) * torch.logspace(-6, 3, 64)[None, :]
+    p = split_pack(w)
+    assert p.dtype == torch.bfloat16 and tuple(p.shape) == (6, 128)
+    v = p.reshape(6, 8, 2, 8).float()
+    hi, lo = v[:, :, 0, :].reshape(6, 64), v[:, :, 1, :].reshape(6, 64)
+    assert torch.equal(hi, w.to(torch.bfloat16).float())
+    assert torch.equal(lo, (w - hi).to(torch.bfloat16).float())
+    assert ((hi + lo - w).abs() <= w.abs() * 2.0 ** -17).all()

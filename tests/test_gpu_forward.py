@@ -39,20 +39,24 @@ def load_case(golden_dir, name):
 def engines():
     from mcgaze_amd.engine import HipEngine
     sd = synth.make_state_dict(0)
-    return {p: HipEngine(sd, precision=p) for p in ('fp32', 'bf16')}
+    return {p: HipEngine(sd, precision=p) for p in ('fp32', 'bf16', 'bf16x3')}
 
 
+PARITY_ENGINES = ['fp32', 'bf16x3']   # both must meet north_star's 1e-3; bf16x3 is the one bench.py times as `parity_engine`
+
+
+@pytest.mark.parametrize('precision', PARITY_ENGINES)
 @pytest.mark.parametrize('name', CASES)
-def test_fp32_engine_matches_reference_golden(golden_dir, engines, name):
+def test_fp32_engine_matches_reference_golden(golden_dir, engines, name, precision):
     g, img, B, T, ishape = load_case(golden_dir, name)
     N = B * T
     hw = np.tile(np.array(ishape[:2], dtype=np.int32), (N, 1))
-    out = engines['fp32'].forward(torch.from_numpy(img).to('cuda:0'), T, img_hw=hw)
+    out = engines[precision].forward(torch.from_numpy(img).to('cuda:0'), T, img_hw=hw)
     torch.cuda.synchronize()
     gaze = out['gaze'].cpu()
     for i, k in enumerate(KEYS):
         d = (orc.yaw_pitch(gaze[i]) - orc.yaw_pitch(g[k])).abs().max().item()
-        print(f'{name} fp32 {k}: max |d(yaw,pitch)| = {d:.2e}')
+        print(f'{name} {precision} {k}: max |d(yaw,pitch)| = {d:.2e}')
         assert d < F32_TOL, (k, d)
     boxes = out['boxes'].cpu()
     if bool(g['rescale']):
@@ -81,7 +85,7 @@ def test_batched_equals_per_clip_bitwise(engines):
     calls exactly (same kernels, same reduction order per output element)."""
     T, B = 7, 5
     img = torch.from_numpy(synth.make_clips(42, B, T)).to('cuda:0')
-    for p in ('fp32', 'bf16'):
+    for p in ('fp32', 'bf16', 'bf16x3'):
         e = engines[p]
         whole = {k: v.clone() for k, v in e.forward(img, T).items()}
         for b in range(B):
@@ -186,12 +190,13 @@ def test_fp32_engine_matches_oracle_on_unusual_shapes(engines, B, T, H, W):
     img = synth.make_clips(100 + T, B, T, H, W)
     metas = synth.make_img_metas(B * T, (H, W, 3))
     want_det, want_gaze = orc.forward(sd, img, metas, T)
-    out = engines['fp32'].forward(torch.from_numpy(img).to('cuda:0'), T)
-    torch.cuda.synchronize()
-    for i, k in enumerate(KEYS):
-        d = (orc.yaw_pitch(out['gaze'][i].cpu()) - orc.yaw_pitch(want_gaze[k])).abs().max().item()
-        assert d < F32_TOL, (k, d)
-    np.testing.assert_allclose(out['boxes'].cpu().numpy(), want_det[..., :4].numpy(), atol=5e-2, rtol=1e-4)
+    for precision in PARITY_ENGINES:
+        out = engines[precision].forward(torch.from_numpy(img).to('cuda:0'), T)
+        torch.cuda.synchronize()
+        for i, k in enumerate(KEYS):
+            d = (orc.yaw_pitch(out['gaze'][i].cpu()) - orc.yaw_pitch(want_gaze[k])).abs().max().item()
+            assert d < F32_TOL, (precision, k, d)
+        np.testing.assert_allclose(out['boxes'].cpu().numpy(), want_det[..., :4].numpy(), atol=5e-2, rtol=1e-4)
     bf = engines['bf16'].forward(torch.from_numpy(img).to('cuda:0'), T)
     assert torch.isfinite(bf['gaze']).all() and (orc.yaw_pitch(bf['gaze'][0].cpu()) - orc.yaw_pitch(want_gaze['gaze_score'])).abs().max().item() < BF16_TOL
 

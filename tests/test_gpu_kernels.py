@@ -90,6 +90,91 @@ def test_conv2d(eng, dtype, case):
     assert scale_err(y.permute(0, 3, 1, 2), ref) < TOL[dtype]
 
 
+X3_TOL = 3e-5   # of the tensor's scale: operands carry 16-17 significant bits (hi + lo), products hi.hi + hi.lo + lo.hi, f32 accumulate
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_bf16x3(eng, case):
+    """The MCG_BF16X3 contraction (f32 activations, split-packed weights, three bf16 MFMAs per product) against the UNQUANTISED
+    f32 convolution: it must sit two orders of magnitude inside the plain bf16 kernel's error."""
+    N, H, W, Cin, Cout, k, stride, pad, relu, resk = case
+    g = torch.Generator().manual_seed(1000 + CONV_CASES.index(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
+    res, mode = None, 0
+    if resk == 'add':
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res.double()
+        mode = 1
+    elif resk == 'up':
+        res = torch.randn(N, Cout, ref.shape[2] // 2, ref.shape[3] // 2, generator=g)
+        ref = ref + F.interpolate(res.double(), size=ref.shape[2:], mode='nearest')
+        mode = 2
+    if relu:
+        ref = F.relu(ref)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to('cuda:0')
+    y = eng.conv2d(nhwc(x), nhwc(w), b.to('cuda:0'), stride=stride, pad=pad, relu=relu,
+                   residual=nhwc(res) if res is not None else None, residual_mode=mode, split=True)
+    torch.cuda.synchronize()
+    err = scale_err(y.permute(0, 3, 1, 2), ref.float())
+    print(f'bf16x3 conv {case}: {err:.2e} of scale')
+    assert err < X3_TOL, err
+
+
+def test_conv2d_bf16x3_randomized_shapes(eng):
+    """The randomized sweep of test_conv2d_randomized_shapes for the bf16x3 kernel (channel counts are multiples of 32: its K tile)."""
+    rs = np.random.RandomState(4048)
+    for trial in range(30):
+        k = int(rs.choice([1, 1, 3, 3, 5]))
+        stride = int(rs.choice([1, 1, 2]))
+        pad = int(rs.choice([0, k // 2])) if k > 1 else 0
+        cin = int(rs.choice([32, 64, 96, 128, 256, 320]))
+        cout = int(rs.choice([32, 64, 72, 128, 256, 640]))
+        N = int(rs.randint(1, 5))
+        H, W = int(rs.randint(max(k, 1), 23)), int(rs.randint(max(k, 1), 23))
+        relu = bool(rs.randint(2))
+        g = torch.Generator().manual_seed(7000 + trial)
+        x = torch.randn(N, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+        b = torch.randn(cout, generator=g)
+        ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad)
+        mode, res = int(rs.randint(3)), None
+        if mode == 1:
+            res = torch.randn(ref.shape, generator=g)
+            ref = ref + res.double()
+        elif mode == 2:
+            hr, wr = max(ref.shape[2] // 2, 1), max(ref.shape[3] // 2, 1)
+            res = torch.randn(N, cout, hr, wr, generator=g)
+            ref = ref + F.interpolate(res.double(), size=ref.shape[2:], mode='nearest')
+        if relu:
+            ref = F.relu(ref)
+        nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to('cuda:0')
+        y = eng.conv2d(nhwc(x), nhwc(w), b.to('cuda:0'), stride=stride, pad=pad, relu=relu,
+                       residual=nhwc(res) if res is not None else None, residual_mode=mode, split=True)
+        torch.cuda.synchronize()
+        err = scale_err(y.permute(0, 3, 1, 2), ref.float())
+        assert err < X3_TOL, (trial, (N, H, W, cin, cout, k, stride, pad, relu, mode), err)
+
+
+@pytest.mark.parametrize('stride2', [1, 2])
+def test_conv3_plus_downsample_bf16x3(eng, stride2):
+    g = torch.Generator().manual_seed(177 + stride2)
+    N, Ho, Wo, planes, inpl, cout = 3, 9, 7, 128, 256, 512
+    o2 = torch.randn(N, planes, Ho, Wo, generator=g)
+    x = torch.randn(N, inpl, Ho * stride2, Wo * stride2, generator=g)
+    w3 = torch.randn(cout, planes, 1, 1, generator=g) / planes ** 0.5
+    wd = torch.randn(cout, inpl, 1, 1, generator=g) / inpl ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(o2.double(), w3.double()) + F.conv2d(x.double(), wd.double(), stride=stride2) + b.double()[None, :, None, None])
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to('cuda:0')
+    wcat = torch.cat([w3, wd], dim=1).permute(0, 2, 3, 1).contiguous().to('cuda:0')
+    y = eng.conv2d(nhwc(o2), wcat, b.to('cuda:0'), relu=True, x2=nhwc(x), stride2=stride2, split=True)
+    torch.cuda.synchronize()
+    assert scale_err(y.permute(0, 3, 1, 2), ref.float()) < X3_TOL
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_conv2d_randomized_shapes(eng, dtype):
     """Seeded sweep over the contraction kernel's paths: ragged row / channel tiles, 1x1 / 3x3 / 5x5 taps, stride 1-2, padding 0-2,
