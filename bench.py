@@ -3,19 +3,30 @@
 
 A "step" is one pass of the whole hot path (R-50 + FPN per frame, 4 decoder stages, gaze head)
 over one batch of synthetic clips already resident in HBM:  --clips-per-gpu clips (default 64 =
-BASELINE.json configs[2]) x 7 frames x 3 x 224 x 224 per GPU, bf16 MFMA engine.  With N > 1 every
-rank processes its own 64 clips (weak scaling, configs[3]: 8 x 64 = 512 clips) and the per-rank
-results are exchanged with ONE fused RCCL all_gather per step.
+BASELINE.json configs[2]) x 7 frames x 3 x 224 x 224 per GPU.  With N > 1 every rank processes its
+own 64 clips (weak scaling, configs[3]: 8 x 64 = 512 clips) -- or, with --global-clips G, its share
+of a FIXED G clips (strong scaling) -- and the per-rank results are exchanged with ONE fused RCCL
+all_gather per step.
+
+One run reports, in ONE JSON line printed by rank 0:
+  * the headline: the --precision engine (default bf16, the configuration north_star's roofline target is quoted on);
+  * `verified`: after the timed loop, the last batch is re-run strictly serially (one trunk stream, no batch pipeline) and
+    must reproduce the timed schedule's outputs BIT FOR BIT;
+  * `parity_engine`: the bf16x3 engine (f32 activations, split-bf16 x 3 MFMA contraction -- the engine that meets north_star's
+    1e-3 on (yaw, pitch)) timed the same way, with its measured deviation from the CPU oracle on clip 0;
+  * `roofline`: dominant contraction kernel, from HIP events around every contraction launch of one UNTIMED sampling step;
+  * `latency_single_clip`: one 7-frame clip per forward (BASELINE.json configs[0], the reference harness's actual usage);
+  * `cpu_baseline`: the fp32 oracle on the host cores (rank 0, N = 1 only), best thread count of a sweep, median of >= 10 forwards.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                 --master-port P bench.py --gpus N --steps K --warmup W
-Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import platform
 import sys
 import time
 
@@ -31,16 +42,14 @@ FLOPS_PER_CLIP_BACKBONE = 57.22e9  # R-50 alone, 8.174 GFLOP per frame (SURVEY.m
 FLOPS_PER_CLIP = 99.55e9          # 2*MAC over convs + linears + bmms, 7x3x224x224 clip
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+PARITY_TOL = 1e-3                 # north_star: (yaw, pitch) within 1e-3 rad of the reference CPU path
 CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,64,128,4,1>', 2: 'igemm_kernel<float,128,128,64,2,2>',
              3: 'igemm_kernel<float,128,128,128,2,2>', 4: 'igemm_kernel<bf16,128,64,64,4,1>', 5: 'igemm_kernel<bf16,128,64,128,4,1>',
              6: 'igemm_kernel<bf16,128,128,64,2,2>', 7: 'igemm_kernel<bf16,128,128,128,2,2>',
              # LDS-DMA pipelined kernel: <dtype, BM, BN, K-slice bytes, waves M, waves N, stages>
-             15: 'igemm_dma_kernel<bf16,256,64,64,4,1,2>', 16: 'igemm_dma_kernel<bf16,128,128,64,2,2,4>',
-             17: 'igemm_dma_kernel<bf16,256,128,64,2,2,3>', 18: 'igemm_dma_kernel<bf16,256,128,64,4,2,3>',
-             19: 'igemm_dma_kernel<bf16,256,256,64,4,2,3>', 24: 'igemm_dma_kernel<bf16,128,128,64,2,2,2>',
-             25: 'igemm_dma_kernel<bf16,256,128,64,4,2,2>', 26: 'igemm_dma_kernel<bf16,128,128,64,2,2,3>',
+             15: 'igemm_dma_kernel<bf16,256,64,64,4,1,2>', 25: 'igemm_dma_kernel<bf16,256,128,64,4,2,2>',
              27: 'igemm_dma_kernel<bf16,128,128,64,4,2,2>', 28: 'igemm_dma_kernel<bf16,256,256,64,4,4,3>',
-             29: 'igemm_dma_kernel<bf16,256,256,64,4,4,2>', 30: 'igemm_dma_kernel<bf16,256,256,128,4,4,2>', 31: 'igemm_dma_kernel<bf16,128,128,64,4,2,3>', 32: 'igemm_dma_kernel<bf16,256,128,64,4,2,3> (<=128 VGPRs)', 40: 'conv3x3_c64_kernel',
+             30: 'igemm_dma_kernel<bf16,256,256,128,4,4,2>', 31: 'igemm_dma_kernel<bf16,128,128,64,4,2,3>', 40: 'conv3x3_c64_kernel',
              # bf16x3 contraction (f32 activations, split-packed weights, 3 bf16 MFMAs per product)
              50: 'igemm_dma_kernel<float,256,256,128,4,2,2,2,x3>', 51: 'igemm_dma_kernel<float,128,128,128,2,2,2,2,x3>', 52: 'igemm_dma_kernel<float,256,64,128,4,1,2,2,x3>'}
 
@@ -48,12 +57,17 @@ CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=250, help='timed steps (default: >= 2 s of timed region at ~10 ms per step)')
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--clips-per-gpu', type=int, default=64)
+    ap.add_argument('--global-clips', type=int, default=0,
+                    help='strong scaling: a FIXED number of clips per step, sharded over the ranks (e.g. 512 = BASELINE.json configs[3]); 0 = weak scaling with --clips-per-gpu')
     ap.add_argument('--clip-length', type=int, default=7)
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
+    ap.add_argument('--parity-engine', default='bf16x3', choices=['bf16x3', 'fp32', 'none'],
+                    help='second engine timed in the same run (the one that meets the 1e-3 parity tolerance); skipped when equal to --precision')
+    ap.add_argument('--parity-steps', type=int, default=0, help='timed steps of the parity engine (0 = max(5, steps // 4))')
     ap.add_argument('--chunk-frames', type=int, default=0)
     ap.add_argument('--workload', default='full', choices=['full', 'backbone_fpn', 'backbone'],
                     help="'full' = BASELINE.json configs[2] (the metric's configuration); 'backbone_fpn' = configs[1], the trunk alone "
@@ -61,39 +75,272 @@ def parse():
     ap.add_argument('--pipeline', type=int, default=1, choices=[0, 1],
                     help='1: two-deep batch pipeline (decoder of step k overlaps trunk of step k+1 on a second stream; '
                          'every batch is fully processed inside the timed region), 0: one stream, strictly serial')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline leg (rank 0, N=1 only); 0 disables')
-    ap.add_argument('--kernel-events', default='first', choices=['first', 'none'],
-                    help="'first': bracket every contraction-kernel launch of the FIRST timed step with HIP events")
+    ap.add_argument('--trunk-streams', type=int, default=2, help='concurrent frame ranges of the trunk (engine option)')
+    ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the cpu_baseline leg (rank 0, N=1 only); 0 disables')
+    ap.add_argument('--latency', type=int, default=1, choices=[0, 1], help='1: report single-clip latency (rank 0, N=1 only)')
+    ap.add_argument('--kernel-events', default='sample', choices=['sample', 'none'],
+                    help="'sample': bracket every contraction-kernel launch of one UNTIMED step with HIP events (roofline)")
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or 'unknown'
+
+
 def cpu_baseline(seconds, clip_length, size):
-    """The CPU oracle (fp32 torch restatement proven equal to the reference, tests/test_oracle.py)
-    timed on the host cores, one clip per forward like the reference harness
-    (tools/test_gaze360_gaze.py:77-111), on a bounded sample of the same synthetic workload."""
+    """The CPU oracle (fp32 torch restatement proven equal to the reference, tests/test_oracle.py) timed on the host cores on a
+    bounded sample of the same synthetic workload: a thread-count sweep picks the fastest setting, then
+    >= 10 timed single-clip forwards (the reference harness's usage, tools/test_gaze360_gaze.py:77-111) and a few 8-clip forwards;
+    medians are reported."""
     from mcgaze_amd import synth
     from oracle import mcgaze_oracle as orc
     sd = orc.as_torch(synth.make_state_dict(0))
     metas = synth.make_img_metas(clip_length, (size, size, 3))
     clips = synth.make_clips(3, 2, clip_length, size, size)
-    orc.forward(sd, clips[:clip_length], metas, clip_length)  # warm-up
-    n, t0 = 0, time.time()
-    while time.time() - t0 < seconds * 2 / 3:
-        orc.forward(sd, clips[(n % 2) * clip_length:(n % 2 + 1) * clip_length], metas, clip_length)
-        n += 1
-    dt = time.time() - t0
-    # second leg (SURVEY.md 8(d)): 8 clips per forward -- what the oracle gains from batching on the same cores
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+
+    def one(i):
+        t = time.perf_counter()
+        orc.forward(sd, clips[(i % 2) * clip_length:(i % 2 + 1) * clip_length], metas, clip_length)
+        return time.perf_counter() - t
+
+    t_start = time.perf_counter()
+    sweep = {}
+    for th in sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu} | {min(default_threads, ncpu)}):
+        torch.set_num_threads(th)
+        one(0)                                   # warm-up at this thread count
+        sweep[th] = min(one(1), one(2))
+        if time.perf_counter() - t_start > seconds * 0.4:
+            break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    one(0)
+    ts = [one(i) for i in range(10)]
+    while time.perf_counter() - t_start < seconds * 0.75 and len(ts) < 40:
+        ts.append(one(len(ts)))
+    med = float(np.median(ts))
     clips8 = synth.make_clips(3, 8, clip_length, size, size)
     metas8 = synth.make_img_metas(8 * clip_length, (size, size, 3))
-    n8, t1 = 0, time.time()
-    while n8 == 0 or time.time() - t1 < seconds / 3:
+    t8 = []
+    for _ in range(3):
+        t = time.perf_counter()
         orc.forward(sd, clips8, metas8, clip_length)
-        n8 += 8
-    dt8 = time.time() - t1
-    return {'value': round(n / dt, 3), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} clips of {clip_length}x3x{size}x{size}, one clip per forward, fp32 oracle (oracle/mcgaze_oracle.py), '
-                      f'{dt:.1f} s on {os.cpu_count()} logical CPUs',
-            'batched8_value': round(n8 / dt8, 3), 'batched8_sample': f'{n8} clips, 8 per forward, {dt8:.1f} s'}
+        t8.append(time.perf_counter() - t)
+        if time.perf_counter() - t_start > seconds * 1.2:
+            break
+    med8 = float(np.median(t8[1:] or t8))
+    torch.set_num_threads(default_threads)
+    return {'value': round(1.0 / med, 3), 'unit': 'clips/s', 'cores': best, 'kind': 'port',
+            'sample': f'{len(ts)} single-clip forwards of {clip_length}x3x{size}x{size} (median {med * 1e3:.0f} ms, min {min(ts) * 1e3:.0f} ms), fp32 oracle '
+                      f'(oracle/mcgaze_oracle.py) with torch.set_num_threads({best}) -- the fastest of the sweep',
+            'thread_sweep_s_per_clip': {str(k): round(v, 3) for k, v in sweep.items()},
+            'logical_cpus': ncpu, 'cpu_model': cpu_model(), 'torch_default_threads': default_threads,
+            'batched8_value': round(8.0 / med8, 3), 'batched8_sample': f'{len(t8)} forwards of 8 clips, median {med8:.2f} s (first is warm-up when more than one)'}
+
+
+_COMM_STREAM = {}
+
+
+def comm_stream(dev):
+    """One exchange stream per device for the whole process (streams are created once and shared: engine.hip, StreamPool)."""
+    if dev.index not in _COMM_STREAM:
+        _COMM_STREAM[dev.index] = torch.cuda.Stream(device=dev, priority=-1)
+    return _COMM_STREAM[dev.index]
+
+
+class Leg:
+    """One engine + its schedule (batch pipeline, result exchange) -- the thing a timed region runs."""
+
+    def __init__(self, a, precision, dev, world, rank, dist, img, B, T):
+        from mcgaze_amd import synth
+        from mcgaze_amd.engine import HipEngine, PipelinedRunner
+        from mcgaze_amd.dist import ResultGather
+        self.a, self.dev, self.dist, self.img, self.B, self.T, self.N = a, dev, dist, img, B, T, B * T
+        self.precision = precision
+        self.eng = HipEngine(synth.make_state_dict(0), precision=precision, device=dev)
+        self.eng.set_option('trunk_streams', a.trunk_streams)
+        self.gathers = [ResultGather(self.N, world, dev) for _ in range(2)]   # results double-buffered like the pipeline
+        self.outs = [g.local_views() for g in self.gathers]                    # the engine writes straight into the fused exchange buffers
+        self.runner = PipelinedRunner(self.eng, self.N, a.size, a.size, T, a.chunk_frames) if a.pipeline and a.workload == 'full' else None
+        # The result exchange runs on its own stream, ordered only after the decoder that produced the slot: on the caller's stream
+        # it would sit between successive submits and serialise batch k+1's trunk behind batch k's decoder (the pipeline's whole point).
+        self.comm = comm_stream(dev) if dist is not None else None
+        self.gathered = [None, None]
+        self.k = 0
+
+    def step(self):
+        a, eng = self.a, self.eng
+        if a.workload == 'backbone_fpn':
+            eng.backbone_fpn(self.img, a.chunk_frames)
+            return
+        if a.workload == 'backbone':
+            eng.backbone_only(self.img)
+            return
+        slot = self.k & 1
+        self.k += 1
+        cur = torch.cuda.current_stream(self.dev)
+        if self.comm is not None and self.gathered[slot] is not None:
+            cur.wait_event(self.gathered[slot])   # the slot's previous exchange has read the buffer the engine is about to rewrite
+        if self.runner is not None:
+            done = self.runner.submit(self.img, self.outs[slot])
+        else:
+            eng.forward(self.img, self.T, chunk_frames=a.chunk_frames, out=self.outs[slot])
+            done = cur.record_event()
+        if self.comm is not None:
+            self.comm.wait_event(done)
+            with torch.cuda.stream(self.comm):
+                self.gathers[slot].all_gather()
+            self.gathered[slot] = self.comm.record_event()
+
+    def drain(self):
+        if self.runner is not None:
+            self.runner.flush()
+        if self.comm is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.comm)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier(device_ids=[self.dev.index])
+        torch.cuda.synchronize(self.dev)
+
+    def serial_forward(self):
+        """The strictly serial schedule: one trunk stream, no batch pipeline, the caller's stream only."""
+        self.eng.set_option('trunk_streams', 1)
+        try:
+            out = self.eng.forward(self.img, self.T, chunk_frames=self.a.chunk_frames)
+            torch.cuda.synchronize(self.dev)
+        finally:
+            self.eng.set_option('trunk_streams', self.a.trunk_streams)
+        return out
+
+    def sample_kernels(self):
+        """Per-launch durations of every contraction launch of ONE untimed step.  The sampled step runs its trunk on ONE stream:
+        with two frame ranges in flight a launch's wall time includes the other range's kernels and says nothing about the kernel."""
+        a, eng = self.a, self.eng
+        eng.set_option('trunk_streams', 1)
+        try:
+            eng.profile_start(4096)
+            if a.workload == 'full':
+                eng.forward(self.img, self.T, chunk_frames=a.chunk_frames)
+            elif a.workload == 'backbone_fpn':
+                eng.backbone_fpn(self.img, a.chunk_frames)
+            else:
+                eng.backbone_only(self.img)
+            torch.cuda.synchronize(self.dev)
+            rec = eng.profile_stop(4096)
+        finally:
+            eng.set_option('trunk_streams', a.trunk_streams)
+        return rec
+
+    def timed(self, steps, warmup):
+        """warmup untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; returns seconds (max over ranks)."""
+        for _ in range(max(warmup, 1)):
+            self.step()
+        self.drain()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.drain()   # the last batch's decoder (and exchange) finishes inside the timed region
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def verify(self):
+        """The timed schedule's last outputs (both pipeline slots) against the strictly serial schedule on the same batch: bitwise."""
+        if self.a.workload != 'full':
+            return None
+        ref = self.serial_forward()
+        slots = [0, 1] if self.k >= 2 else [0]
+        return all(torch.equal(ref[k], self.outs[s][k]) for s in slots for k in ('gaze', 'boxes', 'scores'))
+
+
+def roofline_of(rec, precision):
+    by = {}
+    for t, f, c, _ in rec:
+        d = by.setdefault(c, [0.0, 0.0, 0])
+        d[0] += t; d[1] += f; d[2] += 1
+    if not by:
+        return None
+    dom = max(by, key=lambda c: by[c][0])
+    t_ms, flops, n = by[dom]
+    achieved = flops / (t_ms * 1e-3) / 1e12
+    peak = PEAK_F32_TFLOPS if dom < 4 else PEAK_BF16_TFLOPS
+    traffic, step_bytes, covered = None, 0.0, 0
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        traffic = (tj.get(CFG_NAMES.get(dom, '')) or {}).get('hbm_bytes_per_launch')
+        for c, v in by.items():   # HBM-side bytes of one step's contraction launches: per-symbol PMC average x launches
+            b = (tj.get(CFG_NAMES.get(c, '')) or {}).get('hbm_bytes_per_launch')
+            if b:
+                step_bytes += b * v[2]; covered += v[2]
+    r = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+         'traffic': traffic, 'kernel': CFG_NAMES.get(dom, str(dom)), 'launches_per_step': n,
+         'avg_launch_ms': round(t_ms / n, 4), 'algorithmic_gflop_per_launch': round(flops / n / 1e9, 2),
+         'all_contraction_launches': {CFG_NAMES.get(c, str(c)): {'launches': v[2], 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
+                                      for c, v in sorted(by.items())},
+         'sampled': 'every contraction launch of one UNTIMED step after warm-up, HIP events on the launch stream, trunk on one stream '
+                    '(trunk_streams=1) so a launch\'s duration is its own; the timed steps run two frame ranges on concurrent streams',
+         'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_bench_traffic.sh); bytes per launch'}
+    if precision == 'bf16x3':
+        r['note'] = ('achieved = ALGORITHMIC FLOP/s; the bf16x3 contraction issues three bf16 MFMAs per algorithmic product, so the matrix pipe runs at '
+                     f'{round(3 * achieved, 1)} TFLOP/s = {round(3 * achieved / peak, 4)} of the bf16 peak')
+    if step_bytes:
+        r['hbm_step'] = {'bytes': int(step_bytes), 'contraction_launches_covered': covered, 'of': len(rec), 'peak_GBps': PEAK_HBM_GBPS,
+                         'note': 'divide by ms_per_step for the whole-path HBM rate; stem, RoIAlign and the small decoder kernels are not in it'}
+    return r
+
+
+def oracle_clip0(img_np, T, size):
+    from mcgaze_amd import synth
+    from oracle import mcgaze_oracle as orc
+    _, ref = orc.forward(synth.make_state_dict(0), img_np[:T], synth.make_img_metas(T, (size, size, 3)), T)
+    return orc.yaw_pitch(ref['gaze_score'])
+
+
+def deviation(out, want_yp, T):
+    from oracle import mcgaze_oracle as orc
+    return float((orc.yaw_pitch(out['gaze'][0][:T].float().cpu()) - want_yp).abs().max())
+
+
+def single_clip_latency(precisions, dev, T, size, iters=60):
+    """BASELINE.json configs[0]: one clip per forward, strictly serial, host-synchronised per call (what the reference harness does)."""
+    from mcgaze_amd import synth
+    from mcgaze_amd.engine import HipEngine
+    img = torch.from_numpy(synth.make_clips(5, 1, T, size, size)).to(dev)
+    res = {}
+    for p in precisions:
+        eng = HipEngine(synth.make_state_dict(0), precision=p, device=dev)
+        for _ in range(10):
+            eng.forward(img, T)
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(iters):
+            t = time.perf_counter()
+            eng.forward(img, T)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t)
+        rec = None
+        eng.profile_start(1024)
+        eng.forward(img, T)
+        torch.cuda.synchronize(dev)
+        rec = eng.profile_stop(1024)
+        res[p] = {'ms_per_clip': round(float(np.median(ts)) * 1e3, 3), 'min_ms': round(min(ts) * 1e3, 3), 'clips_per_s': round(1.0 / float(np.median(ts)), 1),
+                  'contraction_launches': len(rec), 'contraction_ms_sum': round(sum(r[0] for r in rec), 3)}
+        del eng
+    return res
 
 
 def main():
@@ -114,135 +361,57 @@ def main():
         os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    from mcgaze_amd import lib as L
     from mcgaze_amd import synth
-    from mcgaze_amd.engine import HipEngine
-    from mcgaze_amd.dist import ResultGather
+    from mcgaze_amd.dist import shard_clips
 
-    if a.workload == 'backbone':
-        os.environ['MCG_TRUNK_STOP'] = 'backbone'
-    lib = L.load()
-    B, T = a.clips_per_gpu, a.clip_length
-    N = B * T
-    eng = HipEngine(synth.make_state_dict(0), precision=a.precision, device=dev)
-    img = torch.from_numpy(synth.make_clips(3 + rank, B, T, a.size, a.size)).to(dev)
-    from mcgaze_amd.engine import PipelinedRunner
-    gathers = [ResultGather(N, world, dev) for _ in range(2)]   # results double-buffered like the pipeline
-    outs = [g.local_views() for g in gathers]                    # the engine writes straight into the fused exchange buffers
-    runner = PipelinedRunner(eng, N, a.size, a.size, T, a.chunk_frames) if a.pipeline and a.workload == 'full' else None
-    eng.forward(img, T, chunk_frames=a.chunk_frames, out=outs[0])
-    state = {'k': 0}
+    T = a.clip_length
+    if a.global_clips > 0:   # strong scaling: this rank's contiguous share of a fixed batch
+        c0, c1 = shard_clips(a.global_clips, world, rank)
+        B, total_per_step, scaling = c1 - c0, a.global_clips, 'strong'
+        assert a.global_clips % world == 0, '--global-clips must be a multiple of the number of GPUs (equal shards keep the result exchange one fused all_gather)'
+    else:
+        B, total_per_step, scaling = a.clips_per_gpu, a.clips_per_gpu * world, 'weak'
+    img_np = synth.make_clips(3 + rank, B, T, a.size, a.size)
+    img = torch.from_numpy(img_np).to(dev)
 
-    # The result exchange runs on its own stream, ordered only after the decoder that produced the slot: on the caller's stream
-    # it would sit between successive submits and serialise batch k+1's trunk behind batch k's decoder (the pipeline's whole point).
-    comm = torch.cuda.Stream(device=dev, priority=-1) if dist is not None else None
-    gathered = [None, None]
-
-    def step():
-        if a.workload != 'full':
-            eng.backbone_fpn(img, a.chunk_frames)
-            return
-        slot = state['k'] & 1
-        state['k'] += 1
-        cur = torch.cuda.current_stream(dev)
-        if comm is not None and gathered[slot] is not None:
-            cur.wait_event(gathered[slot])   # the slot's previous exchange has read the buffer the engine is about to rewrite
-        if runner is not None:
-            done = runner.submit(img, outs[slot])
-        else:
-            eng.forward(img, T, chunk_frames=a.chunk_frames, out=outs[slot])
-            done = cur.record_event()
-        if comm is not None:
-            comm.wait_event(done)
-            with torch.cuda.stream(comm):
-                gathers[slot].all_gather()
-            gathered[slot] = comm.record_event()
-
-    def drain():
-        if runner is not None:
-            runner.flush()
-        if comm is not None:
-            torch.cuda.current_stream(dev).wait_stream(comm)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier(device_ids=[local])
-        torch.cuda.synchronize(dev)
-
-    for _ in range(max(a.warmup, 1)):
-        step()
-    drain()
+    # ------------------------------------------------------------------ headline engine
+    leg = Leg(a, a.precision, dev, world, rank, dist, img, B, T)
+    for _ in range(2):
+        leg.step()
+    leg.drain()
     torch.cuda.synchronize(dev)
-    launches = 0
-    user_streams = os.environ.get('MCG_TRUNK_STREAMS')
-    if a.kernel_events == 'first':  # count contraction-kernel launches per step (untimed), then arm for the first timed step
-        # The sampled step runs its trunk on ONE stream: with two frame ranges in flight (the default, engine.hip) a launch's
-        # wall time includes the other range's kernels and says nothing about the kernel itself.
-        os.environ['MCG_TRUNK_STREAMS'] = '1'
-        cnt = C.c_int()
-        L.check(lib.mcg_profile_start(4096), 'mcg_profile_start')
-        if a.workload == 'full':
-            eng.forward(img, T, chunk_frames=a.chunk_frames, out=outs[0])
-        else:
-            eng.backbone_fpn(img, a.chunk_frames)
+    roofline = roofline_of(leg.sample_kernels(), a.precision) if a.kernel_events == 'sample' else None
+    elapsed = leg.timed(a.steps, a.warmup)
+    verified = leg.verify()
+    want_yp = oracle_clip0(img_np, T, a.size) if (rank == 0 and a.workload == 'full') else None
+    head_dev = deviation(leg.outs[0], want_yp, T) if want_yp is not None else None
+
+    # ------------------------------------------------------------------ parity engine, same protocol
+    parity = None
+    if a.parity_engine not in ('none', a.precision) and a.workload == 'full':
+        del leg.runner
+        leg.runner = None
+        pleg = Leg(a, a.parity_engine, dev, world, rank, dist, img, B, T)
+        for _ in range(2):
+            pleg.step()
+        pleg.drain()
         torch.cuda.synchronize(dev)
-        L.check(lib.mcg_profile_stop(C.byref(cnt), None, None, None, None, 4096), 'mcg_profile_stop')
-        launches = cnt.value
-        L.check(lib.mcg_profile_start(launches), 'mcg_profile_start')
+        proof = roofline_of(pleg.sample_kernels(), a.parity_engine) if a.kernel_events == 'sample' else None
+        psteps = a.parity_steps or max(5, a.steps // 4)
+        pel = pleg.timed(psteps, max(2, a.warmup // 3))
+        pver = pleg.verify()
+        pval = total_per_step * psteps / pel
+        parity = {'dtype': a.parity_engine, 'value': round(pval, 2), 'unit': 'clips/s', 'steps': psteps, 'ms_per_step': round(pel / psteps * 1e3, 3),
+                  'verified': pver, 'model_tflops': round(pval * FLOPS_PER_CLIP / 1e12, 1),
+                  'max_abs_dev_yaw_pitch_clip0': deviation(pleg.outs[0], want_yp, T) if want_yp is not None else None,
+                  'tolerance': PARITY_TOL, 'oracle': 'oracle/mcgaze_oracle.py (fp32 CPU restatement pinned to the reference goldens) on clip 0 of this batch',
+                  'what': 'f32 activations, split-packed bf16 weights, three bf16 MFMAs per product, f32 accumulate (include/mcgaze_hip.h MCG_BF16X3)'
+                          if a.parity_engine == 'bf16x3' else 'f32 storage and f32 MFMA',
+                  'roofline': proof}
+        del pleg
 
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step()
-        if i == 0 and a.kernel_events == 'first':  # sampling done: back to the configured number of concurrent frame ranges
-            if user_streams is None:
-                os.environ.pop('MCG_TRUNK_STREAMS', None)
-            else:
-                os.environ['MCG_TRUNK_STREAMS'] = user_streams
-    drain()  # the last batch's decoder finishes inside the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    roofline = None
-    if a.kernel_events == 'first':
-        cnt = C.c_int()
-        ms = (C.c_float * launches)(); fl = (C.c_double * launches)(); cf = (C.c_int * launches)()
-        L.check(lib.mcg_profile_stop(C.byref(cnt), ms, fl, cf, None, launches), 'mcg_profile_stop')
-        rec = [(ms[i], fl[i], cf[i]) for i in range(cnt.value)]
-        by = {}
-        for t, f, c in rec:
-            d = by.setdefault(c, [0.0, 0.0, 0])
-            d[0] += t; d[1] += f; d[2] += 1
-        dom = max(by, key=lambda c: by[c][0])
-        t_ms, flops, n = by[dom]
-        achieved = flops / (t_ms * 1e-3) / 1e12
-        peak = PEAK_BF16_TFLOPS if dom >= 4 else PEAK_F32_TFLOPS   # bf16x3 (50..52) is priced against the bf16 peak too: it issues 3 bf16 MFMAs per algorithmic product
-        traffic, step_bytes, covered = None, 0.0, 0
-        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = (tj.get(CFG_NAMES[dom]) or {}).get('hbm_bytes_per_launch')
-            for c, v in by.items():   # HBM-side bytes of one step's contraction launches: per-symbol PMC average x launches
-                b = (tj.get(CFG_NAMES.get(c, '')) or {}).get('hbm_bytes_per_launch')
-                if b:
-                    step_bytes += b * v[2]; covered += v[2]
-        roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                    'traffic': traffic, 'kernel': CFG_NAMES[dom], 'launches_per_step': n,
-                    'avg_launch_ms': round(t_ms / n, 4), 'algorithmic_gflop_per_launch': round(flops / n / 1e9, 2),
-                    'all_contraction_launches': {CFG_NAMES[c]: {'launches': v[2], 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
-                                                 for c, v in sorted(by.items())},
-                    'sampled': "every contraction launch of the first timed step, HIP events on the launch stream; that step's trunk runs on one stream (MCG_TRUNK_STREAMS=1) so a launch's duration is its own -- the other steps run two frame ranges on concurrent streams",
-                    'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_bench_traffic.sh); bytes per launch'}
-        if step_bytes:
-            roofline['hbm_step'] = {'bytes': int(step_bytes), 'contraction_launches_covered': covered, 'of': len(rec), 'peak_GBps': PEAK_HBM_GBPS,
-                                    'note': 'divide by ms_per_step for the whole-path HBM rate; stem, RoIAlign and the small decoder kernels are not in it'}
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     if rank == 0:
-        total_clips = B * world * a.steps
+        total_clips = total_per_step * a.steps
         flops_per_clip = {'full': FLOPS_PER_CLIP, 'backbone_fpn': FLOPS_PER_CLIP_TRUNK, 'backbone': FLOPS_PER_CLIP_BACKBONE}[a.workload]
         value = total_clips / elapsed
         if roofline and 'hbm_step' in roofline:
@@ -250,20 +419,30 @@ def main():
             roofline['hbm_step'].update({'achieved_GBps': round(gbps, 1), 'frac': round(gbps / PEAK_HBM_GBPS, 4)})
         line = {
             'metric': 'clips/sec (7x3x224x224)', 'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': a.steps,
-            'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic (seeded N(0,1) clips, random-init weights, resident in HBM)',
-            'config': {'workload': {'full': 'full multiclue_gaze_r50 forward (R-50 + FPN + 4 decoder stages + gaze head), ', 'backbone_fpn': 'R-50 backbone + FPN only (BASELINE.json configs[1]), ', 'backbone': 'R-50 backbone only, C2..C5 (BASELINE.json configs[1]; MCG_TRUNK_STOP=backbone), '}[a.workload] +
-                                   f'{B} clips/GPU x {T} frames x 3x{a.size}x{a.size}, {B * world} clips/step',
-                       'clips_per_gpu': B, 'clip_length': T, 'global_clips': B * world, 'chunk_frames': a.chunk_frames,
+            'config': {'workload': {'full': 'full multiclue_gaze_r50 forward (R-50 + FPN + 4 decoder stages + gaze head), ', 'backbone_fpn': 'R-50 backbone + FPN only (BASELINE.json configs[1]), ', 'backbone': 'R-50 backbone only, C2..C5 (BASELINE.json configs[1]; mcg_bench_backbone_forward), '}[a.workload] +
+                                   f'{B} clips/GPU x {T} frames x 3x{a.size}x{a.size}, {total_per_step} clips/step',
+                       'clips_per_gpu': B, 'clip_length': T, 'global_clips': total_per_step, 'chunk_frames': a.chunk_frames,
                        'parallelism': f'dp{world} (clips sharded by rank, one fused all_gather of results per step)' if world > 1 else 'single GPU',
                        'batch_pipeline': 'decoder(step k) overlaps trunk(step k+1) on a second HIP stream; all K batches complete inside the timed region' if (a.pipeline and a.workload == 'full') else 'none (serial)',
-                       'trunk_streams': int(os.environ.get('MCG_TRUNK_STREAMS', '2'))},
+                       'trunk_streams': a.trunk_streams},
+            'timed_region_s': round(elapsed, 3),
+            'verified': verified,
+            'verified_how': 'after the timed loop the batch is re-run strictly serially (trunk_streams=1, no batch pipeline, one stream); gaze / boxes / scores of both pipeline slots must equal it bit for bit',
+            'max_abs_dev_yaw_pitch_clip0': head_dev,
             'model_tflops': round(value * flops_per_clip / 1e12, 1),
             'frac_of_bf16_mfma_peak': round(value * flops_per_clip / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             'roofline': roofline,
+            'parity_engine': parity,
         }
+        if world == 1 and a.latency and a.workload == 'full':
+            del leg
+            line['latency_single_clip'] = single_clip_latency([p for p in dict.fromkeys([a.precision, a.parity_engine]) if p != 'none'], dev, T, a.size)
         if world == 1 and a.cpu_seconds > 0:
             line['cpu_baseline'] = cpu_baseline(a.cpu_seconds, T, a.size)
+            if 'latency_single_clip' in line:
+                line['latency_single_clip']['cpu_oracle_ms_per_clip'] = round(1e3 / line['cpu_baseline']['value'], 1)
     else:
         line = None
     # The JSON line is the LAST thing on stdout, across all ranks: RCCL writes a banner ("RCCL version ... Librccl path") through C

@@ -60,6 +60,13 @@ int mcg_nhwc_to_nchw(mcg_stream s, mcg_dtype dt, const void* src, float* dst, in
  *   every nn.Linear of the decoder (H=W=1)         gaze_stqi_head.py:151-201, transformer.py:1131-1162
  */
 enum { MCG_RES_NONE = 0, MCG_RES_ADD = 1, MCG_RES_UPSAMPLE_ADD = 2 };
+/* Variant switches of the stand-alone operator entry points (an engine takes the same through mcg_engine_set_option).  The library
+ * reads no environment variable; the default (0) is the product path.  Every variant computes the same function -- the bf16 ones
+ * bit-identically (tests/test_gpu_kernels.py) -- they exist for A/B measurements and for those tests. */
+enum {
+  MCG_FLAG_STAGED_GEMM = 1,     /* bf16: register-staged contraction kernel instead of the LDS-DMA one */
+  MCG_FLAG_NO_SPECIALISED = 2   /* generic launch sequences instead of conv3x3_c64 / the fused stem / the decoder row-block chains */
+};
 typedef struct {
   const void* x;        /* NHWC [N,H,W,Cin]                                         */
   const void* w;        /* OHWI [Cout,KH,KW,Cin]                                    */
@@ -76,6 +83,8 @@ typedef struct {
    * resnet.py:289-298): x2 = the block input, w2 = the BN-folded downsample weight. */
   const void* x2;       /* NHWC [N,H2,W2,Cin2] or NULL */
   int Cin2, stride2, H2, W2;
+  int tile;             /* 0 = heuristic; else force this tile id of the contraction kernel (igemm.hip: 9, 11, 12, 14, 15; bf16x3: 50, 51) */
+  int flags;            /* MCG_FLAG_* */
 } mcg_conv_desc;
 int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);
 
@@ -84,7 +93,7 @@ int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);
  * [64][7][8][4] (kw and channel zero-padded, BN folded).  ws >= mcg_stem_workspace_bytes. */
 size_t mcg_stem_workspace_bytes(mcg_dtype dt, int N, int H, int W);
 int mcg_stem_forward(mcg_stream s, mcg_dtype dt, const float* img, const void* w_stem, const float* bias,
-                     void* y, int N, int H, int W, void* ws, size_t ws_bytes);
+                     void* y, int N, int H, int W, void* ws, size_t ws_bytes, int flags);
 
 /* ---------------------------------------------------------------- RoIAlign, all levels, one launch
  * Replaces SingleRoIExtractor.forward (roi_extractors/single_level_roi_extractor.py:57-115:
@@ -143,7 +152,7 @@ size_t mcg_stage_workspace_bytes(mcg_dtype dt, int num_frames);
 int mcg_stage_forward(mcg_stream s, mcg_dtype dt, const void* const weights[MCG_SW_COUNT], const void* roi_feat,
                       const void* obj_in, const float* boxes_in, int num_frames, int clip_length,
                       void* obj_out, float* boxes_out, float* cls_out, const float bbox_stds[4],
-                      void* ws, size_t ws_bytes);
+                      void* ws, size_t ws_bytes, int flags);
 
 /* GazeHead.forward (mask_heads/gaze_head.py:138-202): obj [N][3][256] dtype -> gaze [4][N][3] f32
  * unit vectors in the order fused, face, eyes, head. */
@@ -181,6 +190,13 @@ typedef struct mcg_engine mcg_engine;
 /* The engine copies the weight TABLES (not the weights); device buffers stay caller-owned. */
 int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, mcg_dtype dt);
 void mcg_engine_destroy(mcg_engine* e);
+/* Per-engine options (integers; unknown names are an error).  An engine is driven by one host thread at a time.
+ *   trunk_streams     1..4  concurrent frame ranges of the trunk (default 2: one range's kernel tails overlap the other's kernels)
+ *   max_range_frames  >= 0  lowers the frames-per-range cap (0 = what fits the 2 GiB descriptor window)
+ *   tile              forces a contraction tile id (0 = heuristic), see mcg_conv_desc.tile
+ *   staged_gemm, conv3x3_c64, stem_fused, decoder_chain   0/1 kernel-variant switches (defaults 0, 1, 1, 1)
+ *   fused_bottleneck  0/1 experimental one-kernel layer1 identity block (default 0) */
+int mcg_engine_set_option(mcg_engine* e, const char* name, int value);
 /* chunk_frames: the trunk runs in chunks of this many frames so that layer outputs stay
  * resident in the 256 MiB Infinity Cache (0 = all frames in one pass). */
 size_t mcg_engine_workspace_bytes(const mcg_engine* e, int num_frames, int H, int W, int chunk_frames);
@@ -220,13 +236,15 @@ typedef struct mcg_frame_desc {
 int mcg_preprocess_frames(mcg_stream stream, const mcg_frame_desc* frames_dev, int num_frames, float* dst, int pad_h, int pad_w,
                           const float mean[3], const float stdinv[3], int to_rgb);
 
-/* ---------------------------------------------------------------- measurement aid (bench.py)
- * While armed, every launch of the implicit-GEMM kernel is bracketed by a hipEvent pair on its
- * launch stream.  mcg_profile_stop synchronises, returns per-launch duration (ms), algorithmic
- * FLOPs, tile-configuration id (bit2: bf16, bit1: BN=128, bit0: 128-byte K slices) and the GEMM
- * shape (M, N, K) of every recorded launch (any output array may be NULL), and disarms. */
-int mcg_profile_start(int capacity);
-int mcg_profile_stop(int* count, float* ms, double* flops, int* cfg, int* shape_mnk, int capacity);
+/* ---------------------------------------------------------------- measurement aids (bench.py)
+ * While armed, every launch of the contraction kernel made by THIS engine is bracketed by a hipEvent pair on its launch stream.
+ * mcg_engine_profile_stop synchronises, returns per-launch duration (ms), algorithmic FLOPs, tile-configuration id (bench.py
+ * CFG_NAMES) and the GEMM shape (M, N, K) of every recorded launch (any output array may be NULL), and disarms. */
+int mcg_engine_profile_start(mcg_engine* e, int capacity);
+int mcg_engine_profile_stop(mcg_engine* e, int* count, float* ms, double* flops, int* cfg, int* shape_mnk, int capacity);
+/* BASELINE.json configs[1] "R-50 backbone-only": stem + layer1..4 (C2..C5 stay in the workspace), no FPN.  Not a product entry
+ * point; ws >= mcg_trunk_workspace_bytes(e, num_frames, H, W, 0). */
+int mcg_bench_backbone_forward(mcg_engine* e, mcg_stream s, const float* img, int num_frames, int H, int W, void* ws, size_t ws_bytes);
 
 #ifdef __cplusplus
 }

@@ -395,10 +395,15 @@ static void launch_attn(hipStream_t s, const void* qkv, void* out, int groups, i
   hipLaunchKernelGGL(attn_core_kernel<T>, dim3(groups), dim3(256), 0, s, (const T*)qkv, (T*)out, L, temporal, clip_len, 1.0f / sqrtf(32.f));
 }
 
-extern "C" int mcg_stage_forward(mcg_stream s_, mcg_dtype dt, const void* const W[MCG_SW_COUNT], const void* roi_feat,
+extern "C" int mcg_stage_forward(mcg_stream s, mcg_dtype dt, const void* const W[MCG_SW_COUNT], const void* roi_feat,
                                  const void* obj_in, const float* boxes_in, int N, int clip_length, void* obj_out,
-                                 float* boxes_out, float* cls_out, const float stds[4], void* ws, size_t ws_bytes) {
-  hipStream_t s = (hipStream_t)s_;
+                                 float* boxes_out, float* cls_out, const float stds[4], void* ws, size_t ws_bytes, int flags) {
+  return stage_forward_ctx((hipStream_t)s, dt, W, roi_feat, obj_in, boxes_in, N, clip_length, obj_out, boxes_out, cls_out, stds, ws, ws_bytes,
+                           McgCtx::from_flags(0, flags));
+}
+int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_COUNT], const void* roi_feat, const void* obj_in,
+                      const float* boxes_in, int N, int clip_length, void* obj_out, float* boxes_out, float* cls_out,
+                      const float stds[4], void* ws, size_t ws_bytes, const McgCtx& ctx) {
   MCG_CHECK_ARG(W && roi_feat && obj_in && boxes_in && obj_out && boxes_out && cls_out && stds && ws, "mcg_stage_forward: null pointer");
   MCG_CHECK_ARG(N > 0 && clip_length > 0 && N % clip_length == 0, "mcg_stage_forward: num_frames=%d is not a multiple of clip_length=%d", N, clip_length);
   for (int i = 0; i < MCG_SW_COUNT; ++i) MCG_CHECK_ARG(W[i], "mcg_stage_forward: weight table entry %d is null", i);
@@ -413,10 +418,9 @@ extern "C" int mcg_stage_forward(mcg_stream s_, mcg_dtype dt, const void* const 
   // --- spatial then temporal self-attention with SHARED weights and LayerNorm (gaze_stqi_head.py:148-166)
   const void* xin = obj_in;
   char* xout[2] = {w.x1, w.x2};
-  const char* env_chain0 = getenv("MCG_CHAIN");
-  const bool chain_attn = bf && !(env_chain0 && env_chain0[0] == '0');
+  const bool chain_attn = bf && ctx.chain;
   for (int pass = 0; pass < 2; ++pass) {
-    MCG_TRY(launch_linear(s, dt, xin, 256, W[MCG_SW_IN_PROJ_W], f32w[MCG_SW_IN_PROJ_B], nullptr, 0, w.qkv, 768, R, 256, 768, 0));
+    MCG_TRY(launch_linear(s, dt, xin, 256, W[MCG_SW_IN_PROJ_W], f32w[MCG_SW_IN_PROJ_B], nullptr, 0, w.qkv, 768, R, 256, 768, 0, ctx));
     if (bf) launch_attn<bf16_t>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
     else launch_attn<float>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
     MCG_CHECK_LAUNCH("attn_core");
@@ -428,18 +432,18 @@ extern "C" int mcg_stage_forward(mcg_stream s_, mcg_dtype dt, const void* const 
       cp.st[0].g = f32w[MCG_SW_ATTN_LN_G]; cp.st[0].b = f32w[MCG_SW_ATTN_LN_B]; cp.st[0].dst = xout[pass]; cp.st[0].from_input = 1;
       if (launch_mlp_chain(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
     } else {
-      MCG_TRY(launch_linear(s, dt, w.att, 256, W[MCG_SW_OUT_PROJ_W], f32w[MCG_SW_OUT_PROJ_B], xin, 256, w.t, 256, R, 256, 256, 0));
+      MCG_TRY(launch_linear(s, dt, w.att, 256, W[MCG_SW_OUT_PROJ_W], f32w[MCG_SW_OUT_PROJ_B], xin, 256, w.t, 256, R, 256, 256, 0, ctx));
       MCG_TRY(launch_ln(s, dt, ln_simple(w.t, f32w[MCG_SW_ATTN_LN_G], f32w[MCG_SW_ATTN_LN_B], 0, xout[pass], R, 256)));
     }
     xin = xout[pass];
   }
   // --- DynamicConv (transformer.py:1116-1164)
-  MCG_TRY(launch_linear(s, dt, w.x2, 256, W[MCG_SW_DYN_W], f32w[MCG_SW_DYN_B], nullptr, 0, w.params, 32768, R, 256, 32768, 0));
+  MCG_TRY(launch_linear(s, dt, w.x2, 256, W[MCG_SW_DYN_W], f32w[MCG_SW_DYN_B], nullptr, 0, w.params, 32768, R, 256, 32768, 0, ctx));
   if (bf) hipLaunchKernelGGL(dynconv_kernel<bf16_t>, dim3(R), dim3(256), 0, s, (const bf16_t*)roi_feat, (const bf16_t*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (bf16_t*)w.feat2);
   else hipLaunchKernelGGL(dynconv_kernel<float>, dim3(R), dim3(256), 0, s, (const float*)roi_feat, (const float*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (float*)w.feat2);
   MCG_CHECK_LAUNCH("dynconv");
   int slabs = 1;
-  MCG_TRY(launch_linear_splitk(s, dt, w.feat2, 12544, W[MCG_SW_FC_W], w.partial, R, 12544, 256, kFcSlices, &slabs));
+  MCG_TRY(launch_linear_splitk(s, dt, w.feat2, 12544, W[MCG_SW_FC_W], w.partial, R, 12544, 256, kFcSlices, &slabs, ctx));
   {
     LnParams p;
     memset(&p, 0, sizeof(p));
@@ -450,11 +454,11 @@ extern "C" int mcg_stage_forward(mcg_stream s_, mcg_dtype dt, const void* const 
     MCG_TRY(launch_ln(s, dt, p));
   }
   // --- FFN (mmcv FFN with add_identity, gaze_stqi_head.py:179-180)
-  MCG_TRY(launch_linear(s, dt, w.x3, 256, W[MCG_SW_FFN1_W], f32w[MCG_SW_FFN1_B], nullptr, 0, w.h, 2048, R, 256, 2048, 1));
+  MCG_TRY(launch_linear(s, dt, w.x3, 256, W[MCG_SW_FFN1_W], f32w[MCG_SW_FFN1_B], nullptr, 0, w.h, 2048, R, 256, 2048, 1, ctx));
   {  // 2048 -> 256 at M = R rows is only a couple of dozen output tiles: split K so the whole chip works on it; the
      // LayerNorm kernel sums the slabs, adds bias and the residual, and normalises (deterministic, no atomics)
     int ffn_slabs = 1;
-    MCG_TRY(launch_linear_splitk(s, dt, w.h, 2048, W[MCG_SW_FFN2_W], w.partial, R, 2048, 256, 8, &ffn_slabs));
+    MCG_TRY(launch_linear_splitk(s, dt, w.h, 2048, W[MCG_SW_FFN2_W], w.partial, R, 2048, 256, 8, &ffn_slabs, ctx));
     LnParams p;
     memset(&p, 0, sizeof(p));
     p.partial = w.partial; p.slabs = ffn_slabs; p.slab_stride = (long long)R * 256; p.bias = f32w[MCG_SW_FFN2_B];
@@ -464,8 +468,7 @@ extern "C" int mcg_stage_forward(mcg_stream s_, mcg_dtype dt, const void* const 
   }
   // --- towers (gaze_stqi_head.py:185-188)
   const void* rin = obj_out;
-  const char* env_chain = getenv("MCG_CHAIN");  // read per call: tests compare the fused chain with the launch sequence below
-  const bool chain = bf && !(env_chain && env_chain[0] == '0');
+  const bool chain = bf && ctx.chain;
   if (chain) {  // cls tower + 3-layer reg tower: eight launches as one (chain.hpp), bit-identical
     ChainParams cp;
     memset(&cp, 0, sizeof(cp));
@@ -481,11 +484,11 @@ extern "C" int mcg_stage_forward(mcg_stream s_, mcg_dtype dt, const void* const 
     if (launch_mlp_chain(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
     rin = w.r1;
   } else {
-    MCG_TRY(launch_linear(s, dt, obj_out, 256, W[MCG_SW_CLS_FC_W], nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0));
+    MCG_TRY(launch_linear(s, dt, obj_out, 256, W[MCG_SW_CLS_FC_W], nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0, ctx));
     MCG_TRY(launch_ln(s, dt, ln_simple(w.c1, f32w[MCG_SW_CLS_LN_G], f32w[MCG_SW_CLS_LN_B], 1, w.clsf, R, 256)));
     char* rbuf[3] = {w.r1, w.r2, w.r1};
     for (int j = 0; j < 3; ++j) {
-      MCG_TRY(launch_linear(s, dt, rin, 256, (const char*)W[MCG_SW_REG_FC_W] + (size_t)j * 65536 * es, nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0));
+      MCG_TRY(launch_linear(s, dt, rin, 256, (const char*)W[MCG_SW_REG_FC_W] + (size_t)j * 65536 * es, nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0, ctx));
       MCG_TRY(launch_ln(s, dt, ln_simple(w.c1, f32w[MCG_SW_REG_LN_G] + j * 256, f32w[MCG_SW_REG_LN_B] + j * 256, 1, rbuf[j], R, 256)));
       rin = rbuf[j];
     }
@@ -502,9 +505,12 @@ extern "C" size_t mcg_gaze_head_workspace_bytes(mcg_dtype dt, int num_frames) {
   return 3 * al256((size_t)6 * num_frames * 256 * es);
 }
 
-extern "C" int mcg_gaze_head(mcg_stream s_, mcg_dtype dt, const void* const W[MCG_GW_COUNT], const void* obj, int N,
+extern "C" int mcg_gaze_head(mcg_stream s, mcg_dtype dt, const void* const W[MCG_GW_COUNT], const void* obj, int N,
                              float* gaze_out, void* ws, size_t ws_bytes) {
-  hipStream_t s = (hipStream_t)s_;
+  return gaze_head_ctx((hipStream_t)s, dt, W, obj, N, gaze_out, ws, ws_bytes, McgCtx());
+}
+int gaze_head_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_GW_COUNT], const void* obj, int N, float* gaze_out,
+                  void* ws, size_t ws_bytes, const McgCtx& ctx) {
   MCG_CHECK_ARG(W && obj && gaze_out && ws && N > 0, "mcg_gaze_head: bad argument");
   for (int i = 0; i < MCG_GW_COUNT; ++i) MCG_CHECK_ARG(W[i], "mcg_gaze_head: weight table entry %d is null", i);
   if (ws_bytes < mcg_gaze_head_workspace_bytes(dt, N)) { mcg_set_error("mcg_gaze_head: workspace too small"); return MCG_ERR_WORKSPACE; }
@@ -524,7 +530,7 @@ extern "C" int mcg_gaze_head(mcg_stream s_, mcg_dtype dt, const void* const W[MC
       else { p.x = h1 + (size_t)k * 3 * N * 256 * es; p.xs_n = 256; p.x_g = (long long)N * 256; }
       p.w = fcw + ((size_t)(k * 3) * 2 + layer) * 65536 * es; p.w_g = 2 * 65536;
       p.y = raw + (size_t)k * 3 * N * 256 * es; p.y_g = (long long)N * 256; p.y_row_stride = 256;
-      MCG_TRY(launch_igemm(s, dt, p, 3));
+      MCG_TRY(launch_igemm(s, dt, p, 3, ctx));
     }
     LnParams q = ln_simple(raw, lg + layer * 256, lb + layer * 256, 1, layer == 0 ? h1 : h2, 6 * N, 256);
     q.rows_per_group = N; q.param_stride = 2 * 256;  // LN params are [6][2][256]

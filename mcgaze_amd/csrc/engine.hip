@@ -2,7 +2,7 @@
 // stage] -> gaze head) from a single C-ABI call, ordered on the caller's HIP stream.  No allocation, no host sync:
 // every intermediate lives in the caller-provided workspace.
 //
-// The trunk of a large batch runs as MCG_TRUNK_STREAMS (default 2) frame ranges on concurrent streams -- the caller's plus
+// The trunk of a large batch runs as `trunk_streams` (option, default 2) frame ranges on concurrent streams -- the caller's plus
 // side streams the engine owns, forked and joined with events so the call still behaves as one operation on the caller's
 // stream.  Frames are independent, so results do not change; what changes is that the last, partly filled round of
 // workgroups of one range's kernel (layer3 at 14x14 has 343 output tiles for 256 CUs) overlaps with the other range's
@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <vector>
 
 int launch_roi_align(hipStream_t s, mcg_dtype dt, const void* const feats[4], const int feat_h[4], const int feat_w[4],
@@ -36,10 +37,50 @@ struct mcg_engine {
   const void* gaze_w[MCG_GW_COUNT];
   float stds[4];
   static constexpr int kMaxSplit = 4, kCandidates = 8;
-  hipStream_t cand[kCandidates] = {};            // side-stream candidates (engine-owned)
-  hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {}, ev_probe[3] = {};
-  std::map<hipStream_t, std::vector<int>> side_of;  // caller stream -> candidates on OTHER hardware queues (probed once)
+  struct StreamPool* pool = nullptr;             // this device's side-stream candidates (shared by every engine on the device)
+  hipStream_t* cand = nullptr;                   // = pool->cand
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {};
+  // options (mcg_engine_set_option) and observers: read at create time or set explicitly, never from the environment
+  McgCtx ctx;                  // kernel-variant switches + profiling sink handed to every launcher
+  Prof prof;                   // per-launch event records (mcg_engine_profile_start / _stop)
+  int trunk_streams = 2;       // concurrent frame ranges of the trunk
+  int max_range_frames = 0;    // 0 = what fits the 2 GiB descriptor window
+  bool fused_block = false;    // experimental one-kernel layer1 identity bottleneck (bottleneck_fused.hpp)
+  std::mutex mu;               // one forward at a time per engine: the fork/join events and side streams are shared state
 };
+// Side-stream candidates are created ONCE per device and shared by every engine of the process.  Measured (tools/leg_order_probe.py):
+// streams created later in a process's life land on hardware queues that serialise against the earlier ones -- a second engine
+// with its own fresh streams ran its trunk 20 % slower than the first (bf16 9.7 -> 11.7 ms per 64 clips) no matter whether the
+// first had been destroyed.  The pool is immutable after creation (guarded by a mutex while it is built and while the per-caller-
+// stream probe result is cached); it lives until process exit.
+struct StreamPool {
+  hipStream_t cand[mcg_engine::kCandidates] = {};
+  hipEvent_t ev_probe[3] = {};
+  std::map<hipStream_t, std::vector<int>> side_of;  // caller stream -> candidates on OTHER hardware queues (probed once)
+  std::mutex mu;
+  bool ok = false;
+};
+static StreamPool* stream_pool_for_current_device() {
+  static std::mutex g_mu;
+  static std::map<int, StreamPool*> g_pools;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_pools.find(dev);
+  if (it != g_pools.end()) return it->second;
+  StreamPool* p = new StreamPool();
+  bool ok = true;
+  // The ROCm runtime packs the streams of a priority level onto at most GPU_MAX_HW_QUEUES (4) hardware queues, and two streams on
+  // one hardware queue execute in submission order INCLUDING each other's event waits: a frame range on a stream that shares a
+  // queue with the caller's runs after it, not beside it (10.1 ms instead of 8.75 for 448 frames).  Which streams share a queue
+  // depends on every stream the process has created, so the pool keeps several candidates and, the first time it sees a caller
+  // stream, measures which of them actually run concurrently with it (side_streams_for).
+  for (int i = 0; i < mcg_engine::kCandidates; ++i) ok = ok && hipStreamCreateWithFlags(&p->cand[i], hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 3; ++i) ok = ok && hipEventCreate(&p->ev_probe[i]) == hipSuccess;
+  p->ok = ok;
+  g_pools[dev] = p;
+  return p;
+}
 // ~150 us of wall clock (s_memrealtime ticks at 100 MHz), one wave
 __global__ void probe_spin_kernel(long long ticks) {
   const long long t0 = wall_clock64();
@@ -48,41 +89,41 @@ __global__ void probe_spin_kernel(long long ticks) {
 // Candidates that run CONCURRENTLY with caller stream s, best effort and cached per stream.  A first-call cost of about a
 // millisecond and a host wait (set-up, not the hot path).
 static const std::vector<int>& side_streams_for(mcg_engine* e, hipStream_t s) {
-  auto it = e->side_of.find(s);
-  if (it != e->side_of.end()) return it->second;
+  StreamPool* p = e->pool;
+  std::lock_guard<std::mutex> lock(p->mu);
+  auto it = p->side_of.find(s);
+  if (it != p->side_of.end()) return it->second;
   std::vector<int> good, rest;
   const long long ticks = 15000;
   for (int c = 0; c < mcg_engine::kCandidates; ++c) {
     bool concurrent = false;
-    if (hipEventRecord(e->ev_probe[0], s) == hipSuccess) {
+    if (hipEventRecord(p->ev_probe[0], s) == hipSuccess) {
       hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, s, ticks);
-      hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, e->cand[c], ticks);
+      hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, p->cand[c], ticks);
       float ms = 0.f;
-      if (hipEventRecord(e->ev_probe[1], s) == hipSuccess && hipEventRecord(e->ev_probe[2], e->cand[c]) == hipSuccess &&
-          hipEventSynchronize(e->ev_probe[1]) == hipSuccess && hipEventSynchronize(e->ev_probe[2]) == hipSuccess &&
-          hipEventElapsedTime(&ms, e->ev_probe[0], e->ev_probe[2]) == hipSuccess)
+      if (hipEventRecord(p->ev_probe[1], s) == hipSuccess && hipEventRecord(p->ev_probe[2], p->cand[c]) == hipSuccess &&
+          hipEventSynchronize(p->ev_probe[1]) == hipSuccess && hipEventSynchronize(p->ev_probe[2]) == hipSuccess &&
+          hipEventElapsedTime(&ms, p->ev_probe[0], p->ev_probe[2]) == hipSuccess)
         concurrent = ms < 0.15f * 1.6f;  // both spins inside ~1.6 spin lengths: they overlapped
     }
     (concurrent ? good : rest).push_back(c);
   }
   (void)hipGetLastError();
   good.insert(good.end(), rest.begin(), rest.end());  // fall back to serialised candidates rather than fail
-  return e->side_of.emplace(s, good).first->second;
+  return p->side_of.emplace(s, good).first->second;
 }
 // Frames per launch sequence are capped so that the largest activation of a range ([n, H/4, W/4, 256]) stays inside the 2 GiB
 // window of the contraction kernel's buffer descriptors (beyond it every conv would fall back to the slower register-staged
-// kernel): 1337 frames at 224x224 bf16.  MCG_MAX_RANGE_FRAMES lowers the cap (tests).
-static int range_frame_cap(mcg_dtype dt, int H, int W) {
-  const long long per_frame = (long long)(H / 4) * (W / 4) * 256 * (dt == MCG_BF16 ? 2 : 4);
+// kernel): 1337 frames at 224x224 bf16.  The `max_range_frames` option lowers the cap (tests).
+static int range_frame_cap(const mcg_engine* e, int H, int W) {
+  const long long per_frame = (long long)(H / 4) * (W / 4) * 256 * (e->dt == MCG_BF16 ? 2 : 4);
   long long cap = 0x7FFFFF00ll / (per_frame > 0 ? per_frame : 1);
-  const char* v = getenv("MCG_MAX_RANGE_FRAMES");
-  if (v && atoi(v) > 0 && atoi(v) < cap) cap = atoi(v);
+  if (e->max_range_frames > 0 && e->max_range_frames < cap) cap = e->max_range_frames;
   return cap < 1 ? 1 : (cap > 0x7fffffff ? 0x7fffffff : (int)cap);
 }
 static const int kMinFramesPerRange = 56;  // below this a range's kernels no longer fill the chip on their own
-static int trunk_ranges(int frames) {
-  const char* v = getenv("MCG_TRUNK_STREAMS");  // read per call (bench.py samples per-launch durations with 1)
-  int k = v ? atoi(v) : 2;
+static int trunk_ranges(const mcg_engine* e, int frames) {
+  int k = e->trunk_streams;
   if (k > mcg_engine::kMaxSplit) k = mcg_engine::kMaxSplit;
   while (k > 1 && frames / k < kMinFramesPerRange) --k;
   return k < 1 ? 1 : k;
@@ -102,6 +143,8 @@ extern "C" int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, m
   }
   MCG_CHECK_ARG(w->num_convs == expect && w->convs, "mcg_engine_create: expected %d bottleneck convs, got %d", expect, w->num_convs);
   MCG_CHECK_ARG(w->num_stages > 0 && w->stage_weights && w->gaze_weights && w->init_boxes && w->init_feats, "mcg_engine_create: decoder tables missing");
+  for (int i = 0; i < w->num_convs; ++i)
+    MCG_CHECK_ARG(w->convs[i].w && w->convs[i].bias, "mcg_engine_create: conv %d has a null pointer", i);
   mcg_engine* e = new mcg_engine();
   e->dt = dt;
   memcpy(e->blocks, w->blocks, sizeof(e->blocks));
@@ -117,38 +160,86 @@ extern "C" int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, m
   memcpy(e->gaze_w, w->gaze_weights, sizeof(e->gaze_w));
   memcpy(e->stds, w->bbox_stds, sizeof(e->stds));
   bool ok = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
-  // Side-stream candidates.  The ROCm runtime packs the streams of a priority level onto at most GPU_MAX_HW_QUEUES (4) hardware
-  // queues, and two streams on one hardware queue execute in submission order INCLUDING each other's event waits: a frame range
-  // on a stream that shares a queue with the caller's runs after it, not beside it (10.1 ms instead of 8.75 for 448 frames,
-  // tools/stream_pairs.py).  Which streams share a queue depends on every stream the process has created (a process group's, a
-  // framework's pool), so the engine keeps several candidates and, the first time it sees a caller stream, measures which of them
-  // actually run concurrently with it (side_streams_for).
-  for (int i = 0; i < mcg_engine::kCandidates; ++i) ok = ok && hipStreamCreateWithFlags(&e->cand[i], hipStreamNonBlocking) == hipSuccess;
+  e->pool = stream_pool_for_current_device();
+  ok = ok && e->pool && e->pool->ok;
+  if (e->pool) e->cand = e->pool->cand;
   for (int i = 0; i < mcg_engine::kMaxSplit - 1; ++i) ok = ok && hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; i < 3; ++i) ok = ok && hipEventCreate(&e->ev_probe[i]) == hipSuccess;
   if (!ok) {
     mcg_engine_destroy(e);
     mcg_set_error("mcg_engine_create: could not create the side streams / events");
     return MCG_ERR_HIP;
   }
-  for (size_t i = 0; i < e->convs.size(); ++i)
-    if (!e->convs[i].w || !e->convs[i].bias) {
-      delete e;
-      mcg_set_error("mcg_engine_create: conv %zu has a null pointer", i);
-      return MCG_ERR_ARG;
-    }
   *out = e;
   return MCG_OK;
+}
+
+// Options.  Everything that used to be an environment switch of the lab bench is an explicit, per-engine setting.
+extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value) {
+  MCG_CHECK_ARG(e && name, "mcg_engine_set_option: null pointer");
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (!strcmp(name, "trunk_streams")) { MCG_CHECK_ARG(value >= 1 && value <= mcg_engine::kMaxSplit, "trunk_streams must be 1..%d", mcg_engine::kMaxSplit); e->trunk_streams = value; }
+  else if (!strcmp(name, "max_range_frames")) { MCG_CHECK_ARG(value >= 0, "max_range_frames must be >= 0"); e->max_range_frames = value; }
+  else if (!strcmp(name, "tile")) e->ctx.tile = value > 0 ? value : -1;
+  else if (!strcmp(name, "staged_gemm")) e->ctx.staged = value != 0;
+  else if (!strcmp(name, "conv3x3_c64")) e->ctx.c64 = value != 0;
+  else if (!strcmp(name, "stem_fused")) e->ctx.stem_fused = value != 0;
+  else if (!strcmp(name, "decoder_chain")) e->ctx.chain = value != 0;
+  else if (!strcmp(name, "fused_bottleneck")) e->fused_block = value != 0;
+  else { mcg_set_error("mcg_engine_set_option: unknown option '%s'", name); return MCG_ERR_ARG; }
+  return MCG_OK;
+}
+
+// Per-launch profiling, owned by the engine: while armed, every contraction launch the engine makes is bracketed by an event pair.
+extern "C" int mcg_engine_profile_start(mcg_engine* e, int capacity) {
+  MCG_CHECK_ARG(e, "mcg_engine_profile_start: null engine");
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (e->prof.recs) { mcg_set_error("mcg_engine_profile_start: already armed"); return MCG_ERR_ARG; }
+  MCG_CHECK_ARG(capacity > 0 && capacity <= (1 << 20), "mcg_engine_profile_start: bad capacity %d", capacity);
+  e->prof.recs = new ProfRec[capacity];
+  for (int i = 0; i < capacity; ++i) {
+    if (hipEventCreate(&e->prof.recs[i].a) != hipSuccess || hipEventCreate(&e->prof.recs[i].b) != hipSuccess) {
+      mcg_set_error("mcg_engine_profile_start: hipEventCreate failed");
+      return MCG_ERR_HIP;
+    }
+  }
+  e->prof.cap = capacity; e->prof.n = 0;
+  e->ctx.prof = &e->prof;
+  return MCG_OK;
+}
+extern "C" int mcg_engine_profile_stop(mcg_engine* e, int* count, float* ms, double* flops, int* cfg, int* shape, int capacity) {
+  MCG_CHECK_ARG(e, "mcg_engine_profile_stop: null engine");
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (!e->prof.recs) { mcg_set_error("mcg_engine_profile_stop: not armed"); return MCG_ERR_ARG; }
+  const int n = e->prof.n;
+  int rc = MCG_OK;
+  for (int i = 0; i < n; ++i) {
+    const ProfRec& r = e->prof.recs[i];
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) rc = MCG_ERR_HIP;
+    if (i < capacity) {
+      if (ms) ms[i] = t;
+      if (flops) flops[i] = r.flops;
+      if (cfg) cfg[i] = r.cfg;
+      if (shape) { shape[3 * i] = r.shape[0]; shape[3 * i + 1] = r.shape[1]; shape[3 * i + 2] = r.shape[2]; }
+    }
+  }
+  for (int i = 0; i < e->prof.cap; ++i) { (void)hipEventDestroy(e->prof.recs[i].a); (void)hipEventDestroy(e->prof.recs[i].b); }
+  delete[] e->prof.recs;
+  e->prof = Prof();
+  e->ctx.prof = nullptr;
+  if (count) *count = n < capacity ? n : capacity;
+  if (rc != MCG_OK) mcg_set_error("mcg_engine_profile_stop: event query failed");
+  return rc;
 }
 extern "C" void mcg_engine_destroy(mcg_engine* e) {
   if (!e) return;
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   for (int i = 0; i < mcg_engine::kMaxSplit - 1; ++i)
     if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
-  for (int i = 0; i < 3; ++i)
-    if (e->ev_probe[i]) (void)hipEventDestroy(e->ev_probe[i]);
-  for (int i = 0; i < mcg_engine::kCandidates; ++i)
-    if (e->cand[i]) (void)hipStreamDestroy(e->cand[i]);
+  if (e->prof.recs) {
+    for (int i = 0; i < e->prof.cap; ++i) { (void)hipEventDestroy(e->prof.recs[i].a); (void)hipEventDestroy(e->prof.recs[i].b); }
+    delete[] e->prof.recs;
+  }
   delete e;
 }
 
@@ -179,22 +270,23 @@ static TrunkWs trunk_layout(mcg_dtype dt, int n, int H, int W, char* base) {
   return t;
 }
 
-static int conv_call(hipStream_t s, mcg_dtype dt, const mcg_conv_weights& cw, const void* x, int n, int h, int w, void* y,
+static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg_conv_weights& cw, const void* x, int n, int h, int w, void* y,
                      int relu, const void* res, int res_mode, int hr, int wr) {
   mcg_conv_desc d;
   memset(&d, 0, sizeof(d));
   d.x = x; d.w = cw.w; d.bias = cw.bias; d.residual = res; d.y = y;
   d.N = n; d.H = h; d.W = w; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.k; d.KW = cw.k; d.stride = cw.stride; d.pad = cw.pad;
   d.relu = relu; d.residual_mode = res_mode; d.Hr = hr; d.Wr = wr;
-  return mcg_conv2d(s, dt, &d);
+  return conv2d_ctx(s, dt, &d, e->ctx);
 }
 
 // Backbone + FPN over frames [f0, f0+n): writes pyramid level i at frame offset f0.
-static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, int n, int H, int W, void* const pyr[4], char* wsbase) {
+static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, int n, int H, int W, void* const pyr[4], char* wsbase,
+                       bool backbone_only = false) {
   const mcg_dtype dt = e->dt;
   const size_t es = esize(dt);
   TrunkWs t = trunk_layout(dt, n, H, W, wsbase);
-  MCG_TRY(mcg_stem_forward(s, dt, img + (size_t)f0 * 3 * H * W, e->stem.w, e->stem.bias, t.x0, n, H, W, t.stem_ws, t.stem_bytes));
+  MCG_TRY(stem_forward_ctx(s, dt, img + (size_t)f0 * 3 * H * W, e->stem.w, e->stem.bias, t.x0, n, H, W, t.stem_ws, t.stem_bytes, e->ctx));
   const void* x = t.x0;
   int h = H / 4, w = W / 4, ci = 0;
   for (int l = 0; l < 4; ++l) {
@@ -203,8 +295,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
       const bool has_ds = b == 0;
       const int ho = (h + 2 * c2.pad - c2.k) / c2.stride + 1, wo = (w + 2 * c2.pad - c2.k) / c2.stride + 1;
       void* y = (b == e->blocks[l] - 1) ? (void*)t.c[l] : (x == t.xa ? (void*)t.xb : (void*)t.xa);
-      const char* fb = getenv("MCG_FUSED_BLOCK");  // read per call: the bit-identity test flips it
-      if (dt == MCG_BF16 && !has_ds && fb && fb[0] == '1' && c1.cin == 256 && c1.cout == 64 && c1.k == 1 && c2.cin == 64 && c2.cout == 64 &&
+      if (dt == MCG_BF16 && !has_ds && e->fused_block && c1.cin == 256 && c1.cout == 64 && c1.k == 1 && c2.cin == 64 && c2.cout == 64 &&
           c2.k == 3 && c2.stride == 1 && c2.pad == 1 && c3.cin == 64 && c3.cout == 256 && c3.k == 1 && c1.bias && c2.bias && c3.bias) {
         // identity bottleneck of layer1 as ONE kernel (bottleneck_fused.hpp): the 64-channel intermediates stay on the CU
         if (launch_bottleneck_fused(s, x, y, c1.w, c1.bias, c2.w, c2.bias, c3.w, c3.bias, n, h, w)) {
@@ -215,8 +306,8 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
         ci += 3;
         continue;
       }
-      MCG_TRY(conv_call(s, dt, c1, x, n, h, w, t.o1, 1, nullptr, MCG_RES_NONE, 0, 0));
-      MCG_TRY(conv_call(s, dt, c2, t.o1, n, h, w, t.o2, 1, nullptr, MCG_RES_NONE, 0, 0));
+      MCG_TRY(conv_call(e, s, dt, c1, x, n, h, w, t.o1, 1, nullptr, MCG_RES_NONE, 0, 0));
+      MCG_TRY(conv_call(e, s, dt, c2, t.o1, n, h, w, t.o2, 1, nullptr, MCG_RES_NONE, 0, 0));
       if (has_ds && e->c3_ds[l].w) {
         // conv3 and the downsample conv as ONE K-concatenated GEMM: relu([o2 | x@stride] . [W3 | Wd]^T + b3 + bd);
         // the downsample output never goes to HBM and conv3 reads no residual.
@@ -226,34 +317,31 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
         d.x = t.o2; d.w = f.w; d.bias = f.bias; d.y = y;
         d.N = n; d.H = ho; d.W = wo; d.Cin = c3.cin; d.Cout = c3.cout; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0; d.relu = 1;
         d.x2 = x; d.Cin2 = e->convs[ci + 3].cin; d.stride2 = e->convs[ci + 3].stride; d.H2 = h; d.W2 = w;
-        MCG_TRY(mcg_conv2d(s, dt, &d));
+        MCG_TRY(conv2d_ctx(s, dt, &d, e->ctx));
       } else {
         const void* identity = x;
         if (has_ds) {
-          MCG_TRY(conv_call(s, dt, e->convs[ci + 3], x, n, h, w, t.ds, 0, nullptr, MCG_RES_NONE, 0, 0));
+          MCG_TRY(conv_call(e, s, dt, e->convs[ci + 3], x, n, h, w, t.ds, 0, nullptr, MCG_RES_NONE, 0, 0));
           identity = t.ds;
         }
-        MCG_TRY(conv_call(s, dt, c3, t.o2, n, ho, wo, y, 1, identity, MCG_RES_ADD, 0, 0));
+        MCG_TRY(conv_call(e, s, dt, c3, t.o2, n, ho, wo, y, 1, identity, MCG_RES_ADD, 0, 0));
       }
       x = y; h = ho; w = wo;
       ci += has_ds ? 4 : 3;
     }
   }
-  {  // measurement switch (bench.py --workload backbone, BASELINE.json configs[1] "backbone-only"): stop after C5, pyramid not written
-    const char* stop = getenv("MCG_TRUNK_STOP");
-    if (stop && !strcmp(stop, "backbone")) return MCG_OK;
-  }
+  if (backbone_only) return MCG_OK;  // mcg_bench_backbone_forward: C2..C5 only
   // FPN (fpn.py:157-180): laterals top-down with the nearest-upsample add fused into the epilogue
   int hs[4], wsz[4];
   for (int i = 0; i < 4; ++i) { hs[i] = (H / 4) >> i; wsz[i] = (W / 4) >> i; }
   for (int i = 3; i >= 0; --i) {
     const void* res = i == 3 ? nullptr : t.l[i + 1];
-    MCG_TRY(conv_call(s, dt, e->lateral[i], t.c[i], n, hs[i], wsz[i], t.l[i], 0, res, res ? MCG_RES_UPSAMPLE_ADD : MCG_RES_NONE,
+    MCG_TRY(conv_call(e, s, dt, e->lateral[i], t.c[i], n, hs[i], wsz[i], t.l[i], 0, res, res ? MCG_RES_UPSAMPLE_ADD : MCG_RES_NONE,
                       i == 3 ? 0 : hs[i + 1], i == 3 ? 0 : wsz[i + 1]));
   }
   for (int i = 0; i < 4; ++i) {
     char* dst = (char*)pyr[i] + (size_t)f0 * hs[i] * wsz[i] * 256 * es;
-    MCG_TRY(conv_call(s, dt, e->fpn_out[i], t.l[i], n, hs[i], wsz[i], dst, 0, nullptr, MCG_RES_NONE, 0, 0));
+    MCG_TRY(conv_call(e, s, dt, e->fpn_out[i], t.l[i], n, hs[i], wsz[i], dst, 0, nullptr, MCG_RES_NONE, 0, 0));
   }
   return MCG_OK;
 }
@@ -288,7 +376,7 @@ extern "C" size_t mcg_trunk_workspace_bytes(const mcg_engine* e, int N, int H, i
   if (chunk < N) return trunk_layout(e->dt, chunk, H, W, nullptr).total;
   // whole batch: one layout per concurrent frame range, sized for the maximum split so the answer does not depend on the environment
   size_t total = 0;
-  const int cap = range_frame_cap(e->dt, H, W);
+  const int cap = range_frame_cap(e, H, W);
   for (int k = 1; k <= mcg_engine::kMaxSplit; ++k) {
     const int per = (N + k - 1) / k < cap ? (N + k - 1) / k : cap;
     const size_t t = (size_t)k * al256(trunk_layout(e->dt, per, H, W, nullptr).total);
@@ -313,23 +401,24 @@ static int check_shape(int N, int H, int W) {
   return MCG_OK;
 }
 
-extern "C" int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s_, const float* img, int N, int H, int W, int chunk,
-                                        void* const pyramid[4], void* ws, size_t ws_bytes) {
-  MCG_CHECK_ARG(e && img && pyramid && ws, "mcg_backbone_fpn_forward: null pointer");
+static int trunk_forward(mcg_engine* e, mcg_stream s_, const float* img, int N, int H, int W, int chunk,
+                         void* const pyramid[4], void* ws, size_t ws_bytes, bool backbone_only) {
+  MCG_CHECK_ARG(e && img && (pyramid || backbone_only) && ws, "mcg_backbone_fpn_forward: null pointer");
   MCG_TRY(check_shape(N, H, W));
+  std::lock_guard<std::mutex> lock(e->mu);
   if (chunk <= 0 || chunk > N) chunk = N;
   const size_t need = mcg_trunk_workspace_bytes(e, N, H, W, chunk);
   if (ws_bytes < need) { mcg_set_error("mcg_backbone_fpn_forward: workspace too small (%zu < %zu)", ws_bytes, need); return MCG_ERR_WORKSPACE; }
   hipStream_t s = (hipStream_t)s_;
   if (chunk < N) {  // sequential frame chunks in a small workspace
-    for (int f0 = 0; f0 < N; f0 += chunk) MCG_TRY(trunk_chunk(e, s, img, f0, (N - f0) < chunk ? (N - f0) : chunk, H, W, pyramid, (char*)ws));
+    for (int f0 = 0; f0 < N; f0 += chunk) MCG_TRY(trunk_chunk(e, s, img, f0, (N - f0) < chunk ? (N - f0) : chunk, H, W, pyramid, (char*)ws, backbone_only));
     return MCG_OK;
   }
-  const int k = trunk_ranges(N);
-  const int cap = range_frame_cap(e->dt, H, W);
+  const int k = trunk_ranges(e, N);
+  const int cap = range_frame_cap(e, H, W);
   const int per = (N + k - 1) / k < cap ? (N + k - 1) / k : cap;
   if (k == 1) {
-    for (int f0 = 0; f0 < N; f0 += per) MCG_TRY(trunk_chunk(e, s, img, f0, (N - f0) < per ? (N - f0) : per, H, W, pyramid, (char*)ws));
+    for (int f0 = 0; f0 < N; f0 += per) MCG_TRY(trunk_chunk(e, s, img, f0, (N - f0) < per ? (N - f0) : per, H, W, pyramid, (char*)ws, backbone_only));
     return MCG_OK;
   }
   // fork: the side streams start after everything already queued on the caller's stream (the input, the previous consumer of
@@ -343,7 +432,7 @@ extern "C" int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s_, const floa
     if (hipStreamWaitEvent(e->cand[sides[i - 1]], e->ev_fork, 0) != hipSuccess) { mcg_set_error("mcg_backbone_fpn_forward: hipStreamWaitEvent failed"); return MCG_ERR_HIP; }
   for (int f0 = 0, i = 0; f0 < N && rc == MCG_OK; f0 += per, i = (i + 1) % k) {
     hipStream_t si = i == 0 ? s : e->cand[sides[i - 1]];
-    rc = trunk_chunk(e, si, img, f0, (N - f0) < per ? (N - f0) : per, H, W, pyramid, (char*)ws + (size_t)i * part_ws);
+    rc = trunk_chunk(e, si, img, f0, (N - f0) < per ? (N - f0) : per, H, W, pyramid, (char*)ws + (size_t)i * part_ws, backbone_only);
   }
   for (int i = 1; i < k; ++i) {  // joined even after a failed launch, so the caller's stream never runs ahead of a side stream
     hipStream_t si = e->cand[sides[i - 1]];
@@ -353,6 +442,16 @@ extern "C" int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s_, const floa
     }
   }
   return rc;
+}
+
+extern "C" int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s, const float* img, int N, int H, int W, int chunk,
+                                        void* const pyramid[4], void* ws, size_t ws_bytes) {
+  return trunk_forward(e, s, img, N, H, W, chunk, pyramid, ws, ws_bytes, false);
+}
+// Measurement entry point (bench.py --workload backbone, BASELINE.json configs[1] "R-50 backbone-only"): the trunk up to C5,
+// no FPN; C2..C5 stay in the workspace.
+extern "C" int mcg_bench_backbone_forward(mcg_engine* e, mcg_stream s, const float* img, int N, int H, int W, void* ws, size_t ws_bytes) {
+  return trunk_forward(e, s, img, N, H, W, 0, nullptr, ws, ws_bytes, true);
 }
 
 extern "C" int mcg_decoder_forward(mcg_engine* e, mcg_stream s_, const void* const pyramid[4], int N, int clip_length, int H, int W,
@@ -372,13 +471,13 @@ extern "C" int mcg_decoder_forward(mcg_engine* e, mcg_stream s_, const void* con
   for (int st = 0; st < e->num_stages; ++st) {
     MCG_TRY(launch_roi_align(s, e->dt, pyramid, fh, fw, strides, 256, b_in, N * 3, 3, c.roi, nullptr));
     float* bdst = (st == e->num_stages - 1) ? boxes_out : b_out;
-    MCG_TRY(mcg_stage_forward(s, e->dt, &e->stage_w[(size_t)st * MCG_SW_COUNT], c.roi, obj_in, b_in, N, clip_length, obj_out, bdst,
-                              c.cls, e->stds, c.stage_ws, c.stage_bytes));
+    MCG_TRY(stage_forward_ctx(s, e->dt, &e->stage_w[(size_t)st * MCG_SW_COUNT], c.roi, obj_in, b_in, N, clip_length, obj_out, bdst,
+                              c.cls, e->stds, c.stage_ws, c.stage_bytes, e->ctx));
     char* t = obj_in; obj_in = obj_out; obj_out = t;
     if (st != e->num_stages - 1) { float* tb = b_in; b_in = b_out; b_out = tb; }
   }
   MCG_TRY(launch_sigmoid(s, c.cls, scores_out, N * 3));
-  MCG_TRY(mcg_gaze_head(s, e->dt, e->gaze_w, obj_in, N, gaze_out, c.gaze_ws, c.gaze_bytes));
+  MCG_TRY(gaze_head_ctx(s, e->dt, e->gaze_w, obj_in, N, gaze_out, c.gaze_ws, c.gaze_bytes, e->ctx));
   return MCG_OK;
 }
 

@@ -35,46 +35,26 @@ extern "C" int mcg_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int
 
 
 // ------------------------------------------------------------------------------------------------
-// Per-launch profiling of the contraction kernel (bench.py's roofline line): when armed, every
-// igemm launch is bracketed by a hipEvent pair on the launch stream and tagged with its
-// algorithmic FLOPs (2*M*Cout*K, true K for the zero-padded stem) and tile configuration.
-struct ProfRec { hipEvent_t a, b; double flops; int cfg; int shape[3]; };
-static ProfRec* g_prof = nullptr;
-static int g_prof_cap = 0, g_prof_n = 0;
-extern "C" int mcg_profile_start(int capacity) {
-  if (g_prof) { mcg_set_error("mcg_profile_start: already armed"); return MCG_ERR_ARG; }
-  MCG_CHECK_ARG(capacity > 0 && capacity <= (1 << 20), "mcg_profile_start: bad capacity %d", capacity);
-  g_prof = new ProfRec[capacity];
-  for (int i = 0; i < capacity; ++i) {
-    if (hipEventCreate(&g_prof[i].a) != hipSuccess || hipEventCreate(&g_prof[i].b) != hipSuccess) {
-      mcg_set_error("mcg_profile_start: hipEventCreate failed");
-      return MCG_ERR_HIP;
-    }
-  }
-  g_prof_cap = capacity; g_prof_n = 0;
-  return MCG_OK;
+// Per-launch profiling of the contraction kernel (bench.py's roofline line): when the context carries an armed Prof, every
+// contraction launch is bracketed by a hipEvent pair on the launch stream and tagged with its algorithmic FLOPs
+// (2*M*Cout*K, true K for the zero-padded stem) and tile configuration.  The records belong to the engine (engine.hip).
+static ProfRec* prof_begin(const McgCtx& ctx, hipStream_t s, int cfg, int M, int N, int K, double flops) {
+  Prof* pr = ctx.prof;
+  if (!pr || pr->n >= pr->cap) return nullptr;
+  ProfRec* rec = &pr->recs[pr->n++];
+  rec->cfg = cfg;
+  rec->shape[0] = M; rec->shape[1] = N; rec->shape[2] = K;
+  rec->flops = flops;
+  (void)hipEventRecord(rec->a, s);
+  return rec;
 }
-extern "C" int mcg_profile_stop(int* count, float* ms, double* flops, int* cfg, int* shape, int capacity) {
-  if (!g_prof) { mcg_set_error("mcg_profile_stop: not armed"); return MCG_ERR_ARG; }
-  const int n = g_prof_n;
-  int rc = MCG_OK;
-  for (int i = 0; i < n; ++i) {
-    float t = 0.f;
-    if (hipEventSynchronize(g_prof[i].b) != hipSuccess || hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) rc = MCG_ERR_HIP;
-    if (i < capacity) {
-      if (ms) ms[i] = t;
-      if (flops) flops[i] = g_prof[i].flops;
-      if (cfg) cfg[i] = g_prof[i].cfg;
-      if (shape) { shape[3 * i] = g_prof[i].shape[0]; shape[3 * i + 1] = g_prof[i].shape[1]; shape[3 * i + 2] = g_prof[i].shape[2]; }
-    }
-  }
-  for (int i = 0; i < g_prof_cap; ++i) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
-  delete[] g_prof;
-  g_prof = nullptr; g_prof_cap = 0; g_prof_n = 0;
-  if (count) *count = n < capacity ? n : capacity;
-  if (rc != MCG_OK) mcg_set_error("mcg_profile_stop: event query failed");
-  return rc;
+static void prof_end(ProfRec* rec, hipStream_t s) {
+  if (rec) (void)hipEventRecord(rec->b, s);
 }
+static double algo_flops(const IgemmParams& p, int groups) {
+  return 2.0 * p.M * p.Cout * (p.algo_k > 0 ? (double)p.algo_k : (double)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0)) * groups;
+}
+static int gemm_k(const IgemmParams& p) { return p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0); }
 
 template <typename T, int BM, int BN, int BKB, int WM, int WN>
 static void launch_cfg(hipStream_t s, const IgemmParams& p, int groups) {
@@ -103,72 +83,54 @@ static bool dma_eligible(const IgemmParams& p, int es) {
   return x_extent > 0 && x_extent < MCG_DMA_MAX_BYTES && w_extent < MCG_DMA_MAX_BYTES && (p.nocheck || p.KH * p.KW <= 32);
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
+// Tile ids of igemm_dma_kernel for Cout > 64 (bf16) -- the ones the heuristic chooses; all walk K in the same order and are
+// bit-identical to each other (tests/test_gpu_kernels.py::test_every_dma_tile_is_bit_identical forces each through `tile`).
+//    9 = 256x128  8 waves, 64-byte K slices, 2 stages (48 -> 64 KiB LDS, two workgroups per CU): the default
+//   11 = 128x128  8 waves, 2 stages: M <= 4096 rows (decoder linears)
+//   15 = 128x128  8 waves, 3 stages: few workgroups (7x7 maps)
+//   12 = 256x256 16 waves, 64-byte slices, 3 stages: Cout % 256 == 0, K >= 384, second source or Cin % 64 != 0
+//   14 = 256x256 16 waves, 128-byte slices, 2 stages: the deep layers (3x3s, layer3/4 conv1): fewest LDS-DMA bytes per FLOP
+// What the sweeps said (profiles/r01_d_tile_sweep.md, r01_f_tile_sweep.md, r01_i_tile16.md): occupancy beats tile size until the
+// grid drops to about one workgroup per CU; 256x256 wins where K is deep and N fills it.
+static const int kT12Min = 320, kT9Min = 300, kT14MinK = 384;
+static bool tile_ok(int tile, const IgemmParams& p, int es) {
+  if (tile == 9 || tile == 11 || tile == 15 || tile == 12) return true;
+  return tile == 14 && (p.Cin * es) % 128 == 0 && !p.x2;
 }
 
 template <typename T>
-static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
+static int launch_typed(hipStream_t s, const IgemmParams& p, int groups, const McgCtx& ctx) {
   constexpr int ES = (int)sizeof(T);
-  // tuning knobs (experiments): MCG_IGEMM=1 selects the register-staged kernel for bf16 too,
-  // MCG_FORCE_NARROW=1 its 64-byte K slices, MCG_TILE=1 the 256x128 DMA tile.
-  static const int use_v1 = env_int("MCG_IGEMM", 0), force_narrow = env_int("MCG_FORCE_NARROW", 0), wide16 = env_int("MCG_WIDE16", 1);
-  const int big_tile = env_int("MCG_TILE", -1);
-  static const int t12_min = env_int("MCG_T12_MIN", 320), t9_min = env_int("MCG_T9_MIN", 300), t14_min = env_int("MCG_T14_MIN", 384);  // read per call: tests and tools/tile_sweep.sh switch tiles inside one process
-  const bool dma = ES == 2 && !use_v1 && dma_eligible(p, ES);
-  const bool wide = !force_narrow && (p.Cin * ES) % 128 == 0 && (!p.x2 || (p.Cin2 * ES) % 128 == 0);
+  const bool dma = ES == 2 && !ctx.staged && dma_eligible(p, ES);
+  const bool wide = (p.Cin * ES) % 128 == 0 && (!p.x2 || (p.Cin2 * ES) % 128 == 0);
   MCG_CHECK_ARG((p.Cin * ES) % 64 == 0 && (!p.x2 || (p.Cin2 * ES) % 64 == 0), "igemm: Cin=%d must be a multiple of %d elements", p.Cin, 64 / ES);
   MCG_CHECK_ARG(p.Cout % (16 / ES) == 0, "igemm: Cout=%d must be a multiple of %d", p.Cout, 16 / ES);
-  // DMA tile choice (profiles/r01_d_tile_sweep.md, r01_f_tile_sweep.md).  What the sweeps say: occupancy beats tile size --
-  // 256x128 with 8 waves and a 2-stage ring (48 KiB LDS, 2 workgroups = 16 waves per CU) wins wherever the grid still has
-  // more than a workgroup per CU; below that 128x128 (twice the workgroups), with a 3-stage ring for the decoder's few-row
-  // linears.  MCG_TILE >= 0 overrides.
-  //   0 = 128x128 4w 4 stages   1 = 256x128 4w 3st   2 = 256x128 8w 3st   3 = 256x256 8w 3st
-  //   8 = 128x128 4w 2st        9 = 256x128 8w 2st   10 = 128x128 4w 3st   12 = 256x256 16w 3st (one 1024-thread workgroup per CU)
-  //   11 = 128x128 8w 2st      15 = 128x128 8w 3st   16 = 256x128 8w 3st capped at 128 VGPRs: 5-10 % faster than 9 / 12 on the K = 512..2304,
-  //   N <= 256 layers one launch at a time, but not once two frame ranges run concurrently (profiles/r01_i_tile16.md) -- not chosen
-  //   21 / 22 = 256x256 8w (64x128 / 128x64 wave tiles, fragments double-buffered in registers), 128-byte K slices, 2st: 2-3 % behind 14
-  //   at the same package power (profiles/r01_j_power.md) -- sweep options only
-  //   14 = 256x256 16w, 128-byte K slices, 2st: half the barriers of 12 per K; +3 % on the K >= 1000 layers (3x3s, layer3/4 conv1), neutral
-  //   below; taken wherever 12 would be and the channel count allows 128-byte slices (MCG_T14_MIN = smallest K, 0 = never)
-  int tile = 8;
+  int tile = 9;
   if (dma && p.Cout > 64) {
     const long long blocks9 = (long long)((p.M + 255) / 256) * ((p.Cout + 127) / 128);
-    const long long Kdim = (long long)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
-    if (big_tile >= 0) tile = big_tile;
-    else if (wide16 && p.Cout % 256 == 0 && Kdim >= 384 && blocks9 >= t12_min) tile = (t14_min > 0 && Kdim >= t14_min && (p.Cin * ES) % 128 == 0 && !p.x2) ? 14 : 12;  // deep K, full 256-wide N blocks: fewest LDS-DMA bytes per FLOP
-    else tile = blocks9 >= t9_min ? 9 : (p.M <= 4096 ? 11 : 15);  // few rows: 128x128 tiles with 8 waves (32x64 wave tiles, ~85 VGPRs)
+    const long long Kdim = gemm_k(p);
+    if (ctx.tile >= 0) {
+      MCG_CHECK_ARG(tile_ok(ctx.tile, p, ES), "igemm: tile %d is not available for this problem (Cin=%d%s)", ctx.tile, p.Cin, p.x2 ? ", second source" : "");
+      tile = ctx.tile;
+    } else if (p.Cout % 256 == 0 && Kdim >= 384 && blocks9 >= kT12Min) {
+      tile = (Kdim >= kT14MinK && tile_ok(14, p, ES)) ? 14 : 12;
+    } else {
+      tile = blocks9 >= kT9Min ? 9 : (p.M <= 4096 ? 11 : 15);
+    }
   }
+  // cfg ids (bench.py CFG_NAMES): 0..3 f32 register-staged, 4..7 bf16 register-staged, 15 = 256x64 DMA, 16 + tile = DMA tiles
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
-  ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
-  if (rec) {
-    rec->cfg = cfg;
-    rec->shape[0] = p.M; rec->shape[1] = p.Cout * groups; rec->shape[2] = p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
-    rec->flops = 2.0 * p.M * p.Cout * (p.algo_k > 0 ? (double)p.algo_k : (double)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0)) * groups;
-    (void)hipEventRecord(rec->a, s);
-  }
+  ProfRec* rec = prof_begin(ctx, s, cfg, p.M, p.Cout * groups, gemm_k(p), algo_flops(p, groups));
   if (dma) {
     if (p.Cout <= 64) {  // 256x64 tile, 4 waves, 2 stages; the register-capped variant (4 workgroups/CU) pays for long-K (3x3) layers
-      if (big_tile == 23) launch_dma<T, 128, 64, 64, 4, 1, 4>(s, p, groups);
-      else if ((long long)p.KH * p.KW * p.Cin >= 512) launch_dma<T, 256, 64, 64, 4, 1, 2, 4>(s, p, groups);
+      if ((long long)p.KH * p.KW * p.Cin >= 512) launch_dma<T, 256, 64, 64, 4, 1, 2, 4>(s, p, groups);
       else launch_dma<T, 256, 64, 64, 4, 1, 2>(s, p, groups);
     }
-    else if (tile == 1) launch_dma<T, 256, 128, 64, 2, 2, 3>(s, p, groups);
-    else if (tile == 2) launch_dma<T, 256, 128, 64, 4, 2, 3>(s, p, groups);
-    else if (tile == 3) launch_dma<T, 256, 256, 64, 4, 2, 3>(s, p, groups);
-    else if (tile == 8) launch_dma<T, 128, 128, 64, 2, 2, 2>(s, p, groups);
     else if (tile == 9) launch_dma<T, 256, 128, 64, 4, 2, 2>(s, p, groups);
-    else if (tile == 10) launch_dma<T, 128, 128, 64, 2, 2, 3>(s, p, groups);
     else if (tile == 11) launch_dma<T, 128, 128, 64, 4, 2, 2>(s, p, groups);
     else if (tile == 15) launch_dma<T, 128, 128, 64, 4, 2, 3>(s, p, groups);
-    else if (tile == 16) launch_dma<T, 256, 128, 64, 4, 2, 3, 4>(s, p, groups);
     else if (tile == 12) launch_dma<T, 256, 256, 64, 4, 4, 3, 4>(s, p, groups);
-    else if (tile == 13) launch_dma<T, 256, 256, 64, 4, 4, 2, 4>(s, p, groups);
-    else if (tile == 14 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 4, 2, 4>(s, p, groups);
-    else if (tile == 21 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 4, 2, 2, 2>(s, p, groups);
-    else if (tile == 22 && (p.Cin * ES) % 128 == 0 && !p.x2) launch_dma<T, 256, 256, 128, 2, 4, 2, 2>(s, p, groups);
-    else launch_dma<T, 128, 128, 64, 2, 2, 4>(s, p, groups);
+    else launch_dma<T, 256, 256, 128, 4, 4, 2, 4>(s, p, groups);
   } else if (p.Cout <= 64) {
     if (wide) launch_cfg<T, 128, 64, 128, 4, 1>(s, p, groups);
     else launch_cfg<T, 128, 64, 64, 4, 1>(s, p, groups);
@@ -176,7 +138,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
     if (wide) launch_cfg<T, 128, 128, 128, 2, 2>(s, p, groups);
     else launch_cfg<T, 128, 128, 64, 2, 2>(s, p, groups);
   }
-  if (rec) (void)hipEventRecord(rec->b, s);
+  prof_end(rec, s);
   MCG_CHECK_LAUNCH("igemm launch");
   return MCG_OK;
 }
@@ -185,7 +147,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups) {
 //   50 = 256x256 8 waves (64x128 wave tiles: the A split is shared by four column tiles), 2 stages, 128 KiB -- deep, wide layers
 //   51 = 128x128 4 waves, 2 stages, 64 KiB (two workgroups per CU) -- Cout < 256, few rows (7x7 maps, decoder linears)
 //   52 = 256x64 4 waves -- Cout <= 64
-static int launch_x3(hipStream_t s, const IgemmParams& p, int groups) {
+static int launch_x3(hipStream_t s, const IgemmParams& p, int groups, const McgCtx& ctx) {
   MCG_CHECK_ARG(p.Cin % 32 == 0 && (!p.x2 || p.Cin2 % 32 == 0), "igemm (bf16x3): Cin=%d must be a multiple of 32", p.Cin);
   MCG_CHECK_ARG(p.Cout % 4 == 0, "igemm (bf16x3): Cout=%d must be a multiple of 4", p.Cout);
   if (!dma_eligible(p, 4)) {
@@ -193,26 +155,21 @@ static int launch_x3(hipStream_t s, const IgemmParams& p, int groups) {
     return MCG_ERR_UNSUPPORTED;
   }
   const long long t256 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
-  const int tile = p.Cout <= 64 ? 52 : (p.Cout % 256 == 0 && t256 >= 200 ? 50 : 51);
-  ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
-  if (rec) {
-    rec->cfg = tile;
-    rec->shape[0] = p.M; rec->shape[1] = p.Cout * groups; rec->shape[2] = p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
-    rec->flops = 2.0 * p.M * p.Cout * (p.algo_k > 0 ? (double)p.algo_k : (double)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0)) * groups;
-    (void)hipEventRecord(rec->a, s);
-  }
+  int tile = p.Cout <= 64 ? 52 : (p.Cout % 256 == 0 && t256 >= 200 ? 50 : 51);
+  if (ctx.tile >= 50 && ctx.tile <= 51 && p.Cout > 64) tile = ctx.tile;
+  ProfRec* rec = prof_begin(ctx, s, tile, p.M, p.Cout * groups, gemm_k(p), algo_flops(p, groups));
   if (tile == 50) launch_dma<float, 256, 256, 128, 4, 2, 2, 2, 1>(s, p, groups);
   else if (tile == 51) launch_dma<float, 128, 128, 128, 2, 2, 2, 2, 1>(s, p, groups);
   else launch_dma<float, 256, 64, 128, 4, 1, 2, 2, 1>(s, p, groups);
-  if (rec) (void)hipEventRecord(rec->b, s);
+  prof_end(rec, s);
   MCG_CHECK_LAUNCH("igemm (bf16x3) launch");
   return MCG_OK;
 }
 
-int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p, int groups) {
+int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p, int groups, const McgCtx& ctx) {
   MCG_CHECK_ARG(p.M > 0 && p.Cout > 0 && groups > 0, "igemm: empty problem (M=%d Cout=%d groups=%d)", p.M, p.Cout, groups);
-  if (dt == MCG_BF16X3) return launch_x3(s, p, groups);
-  return dt == MCG_BF16 ? launch_typed<bf16_t>(s, p, groups) : launch_typed<float>(s, p, groups);
+  if (dt == MCG_BF16X3) return launch_x3(s, p, groups, ctx);
+  return dt == MCG_BF16 ? launch_typed<bf16_t>(s, p, groups, ctx) : launch_typed<float>(s, p, groups, ctx);
 }
 
 static IgemmParams linear_params(const void* x, long long lda, const void* w, int M, int K, int Cout) {
@@ -226,20 +183,21 @@ static IgemmParams linear_params(const void* x, long long lda, const void* w, in
 }
 
 int launch_linear(hipStream_t s, mcg_dtype dt, const void* x, long long lda, const void* w, const float* bias,
-                  const void* res, long long ldres, void* y, long long ldy, int M, int K, int Cout, int relu) {
+                  const void* res, long long ldres, void* y, long long ldy, int M, int K, int Cout, int relu, const McgCtx& ctx) {
   IgemmParams p = linear_params(x, lda, w, M, K, Cout);
   p.bias = bias; p.res = res; p.y = y;
   p.y_row_stride = ldy; p.res_row_stride = ldres;
   p.relu = relu; p.res_mode = res ? MCG_RES_ADD : MCG_RES_NONE;
-  return launch_igemm(s, dt, p, 1);
+  return launch_igemm(s, dt, p, 1, ctx);
 }
 
 int launch_linear_splitk(hipStream_t s, mcg_dtype dt, const void* x, long long lda, const void* w, float* partial,
-                         int M, int K, int Cout, int want_slices, int* splitk_out) {
+                         int M, int K, int Cout, int want_slices, int* splitk_out, const McgCtx& ctx) {
   IgemmParams p = linear_params(x, lda, w, M, K, Cout);
   const int es = dt == MCG_BF16 ? 2 : 4;
-  const bool dma = dt == MCG_BF16 && !env_int("MCG_IGEMM", 0);
-  const int bk = dt == MCG_BF16X3 ? 32 : (dma || env_int("MCG_FORCE_NARROW", 0) ? 64 : (((long long)K * es) % 128 == 0 ? 128 : 64)) / es;
+  const bool dma = dt == MCG_BF16 && !ctx.staged;
+  // K elements per K-tile of the kernel that will run: 32 (bf16x3), 64-byte slices (bf16 DMA), 128- or 64-byte slices (register-staged)
+  const int bk = dt == MCG_BF16X3 ? 32 : (dma ? 64 : (((long long)K * es) % 128 == 0 ? 128 : 64)) / es;
   const int KT = K / bk;
   int slices = want_slices < 1 ? 1 : (want_slices > KT ? KT : want_slices);
   const int per = (KT + slices - 1) / slices;
@@ -248,10 +206,10 @@ int launch_linear_splitk(hipStream_t s, mcg_dtype dt, const void* x, long long l
   p.splitk = slices; p.tiles_per_slice = per;
   if (slices == 1) p.splitk = 2;  // force the slab path; slice 1 is empty and writes zeros
   *splitk_out = p.splitk;
-  return launch_igemm(s, dt, p, 1);
+  return launch_igemm(s, dt, p, 1, ctx);
 }
 
-extern "C" int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d) {
+int conv2d_ctx(hipStream_t s, mcg_dtype dt, const mcg_conv_desc* d, const McgCtx& ctx) {
   MCG_CHECK_ARG(d && d->x && d->w && d->y, "mcg_conv2d: null pointer");
   MCG_CHECK_ARG(d->stride >= 1 && d->KH >= 1 && d->KW >= 1, "mcg_conv2d: bad geometry");
   IgemmParams p;
@@ -279,21 +237,20 @@ extern "C" int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d) {
     p.xs2_w = d->Cin2; p.xs2_h = (long long)d->W2 * d->Cin2; p.xs2_n = (long long)d->H2 * d->W2 * d->Cin2;
   }
   p.splitk = 1; p.tiles_per_slice = 1 << 30;
-  if (dt == MCG_BF16 && d->bias && conv3x3_c64_applicable(d->KH, d->KW, d->stride, d->pad, d->Cin, d->Cout, p.res_mode != MCG_RES_NONE, d->x2 != nullptr) &&
-      env_int("MCG_C64", 1)) {  // layer1's conv2: window staged once, nine taps by address (conv3x3_c64.hpp); bit-identical
-    ProfRec* rec = (g_prof && g_prof_n < g_prof_cap) ? &g_prof[g_prof_n++] : nullptr;
-    if (rec) {
-      rec->cfg = 40;
-      rec->shape[0] = p.M; rec->shape[1] = 64; rec->shape[2] = 576;
-      rec->flops = 2.0 * p.M * 64 * 576;
-      (void)hipEventRecord(rec->a, (hipStream_t)s);
-    }
-    const int rc = launch_conv3x3_c64((hipStream_t)s, d->x, d->w, d->bias, d->y, d->N, d->H, d->W, d->relu);
-    if (rec) (void)hipEventRecord(rec->b, (hipStream_t)s);
+  if (dt == MCG_BF16 && d->bias && ctx.c64 && !ctx.staged && ctx.tile < 0 &&
+      conv3x3_c64_applicable(d->KH, d->KW, d->stride, d->pad, d->Cin, d->Cout, p.res_mode != MCG_RES_NONE, d->x2 != nullptr)) {
+    // layer1's conv2: window staged once, nine taps by address (conv3x3_c64.hpp); bit-identical to the generic kernel
+    ProfRec* rec = prof_begin(ctx, s, 40, p.M, 64, 576, 2.0 * p.M * 64 * 576);
+    const int rc = launch_conv3x3_c64(s, d->x, d->w, d->bias, d->y, d->N, d->H, d->W, d->relu);
+    prof_end(rec, s);
     if (rc) { mcg_set_error("conv3x3_c64 launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
   }
-  return launch_igemm((hipStream_t)s, dt, p, 1);
+  return launch_igemm(s, dt, p, 1, ctx);
+}
+extern "C" int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d) {
+  MCG_CHECK_ARG(d, "mcg_conv2d: null descriptor");
+  return conv2d_ctx((hipStream_t)s, dt, d, McgCtx::from_flags(d->tile, d->flags));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -364,17 +321,19 @@ extern "C" size_t mcg_stem_workspace_bytes(mcg_dtype dt, int N, int H, int W) {
   return ((packed + 255) / 256) * 256 + ((conv + 255) / 256) * 256;
 }
 
-extern "C" int mcg_stem_forward(mcg_stream s_, mcg_dtype dt, const float* img, const void* w_stem, const float* bias,
-                                void* y, int N, int H, int W, void* ws, size_t ws_bytes) {
-  hipStream_t s = (hipStream_t)s_;
+extern "C" int mcg_stem_forward(mcg_stream s, mcg_dtype dt, const float* img, const void* w_stem, const float* bias,
+                                void* y, int N, int H, int W, void* ws, size_t ws_bytes, int flags) {
+  return stem_forward_ctx((hipStream_t)s, dt, img, w_stem, bias, y, N, H, W, ws, ws_bytes, McgCtx::from_flags(0, flags));
+}
+int stem_forward_ctx(hipStream_t s, mcg_dtype dt, const float* img, const void* w_stem, const float* bias, void* y, int N, int H, int W,
+                     void* ws, size_t ws_bytes, const McgCtx& ctx) {
   MCG_CHECK_ARG(img && w_stem && y && ws, "mcg_stem_forward: null pointer");
   MCG_CHECK_ARG(H % 4 == 0 && W % 4 == 0, "mcg_stem_forward: H, W must be multiples of 4 (got %dx%d)", H, W);
   if (ws_bytes < mcg_stem_workspace_bytes(dt, N, H, W)) {
     mcg_set_error("mcg_stem_forward: workspace too small (%zu < %zu)", ws_bytes, mcg_stem_workspace_bytes(dt, N, H, W));
     return MCG_ERR_WORKSPACE;
   }
-  const int fused = env_int("MCG_STEM_FUSED", 1);  // read per call: tests flip it to compare the two paths
-  if (dt == MCG_BF16 && fused) {  // one kernel, no conv-map round trip (stem_fused.hpp); bit-identical to the path below
+  if (dt == MCG_BF16 && ctx.stem_fused) {  // one kernel, no conv-map round trip (stem_fused.hpp); bit-identical to the path below
     if (launch_stem_fused(s, img, w_stem, bias, y, N, H, W)) { mcg_set_error("stem_fused launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
   }
@@ -393,7 +352,7 @@ extern "C" int mcg_stem_forward(mcg_stream s_, mcg_dtype dt, const float* img, c
   p.xs_w = 4; p.xs_h = (long long)Wp * 4; p.xs_n = (long long)Hp * Wp * 4; p.nocheck = 1;
   p.y_row_stride = 64; p.relu = 1; p.res_mode = MCG_RES_NONE; p.splitk = 1; p.tiles_per_slice = 1 << 30;
   p.algo_k = 147;  // 7*7*3 real taps; the packed K of 224 carries zero weights
-  MCG_TRY(launch_igemm(s, dt, p, 1));
+  MCG_TRY(launch_igemm(s, dt, p, 1, ctx));
   const int Ho = (Hc + 2 - 3) / 2 + 1, Wo = (Wc + 2 - 3) / 2 + 1;
   const long long nchunks = (long long)N * Ho * Wo * (64 / (16 / (int)es));
   if (dt == MCG_BF16) hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(grid_for(nchunks, 256)), dim3(256), 0, s, (const bf16_t*)conv, (bf16_t*)y, N, Hc, Wc, 64, Ho, Wo);

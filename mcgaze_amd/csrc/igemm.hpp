@@ -257,11 +257,45 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Launch context: everything that selects a kernel VARIANT or observes launches.  It travels explicitly from the C-ABI entry
+// point down to the launchers -- the library reads no environment variable and keeps no mutable process-global state.
+// An engine owns one (mcg_engine_set_option / mcg_engine_profile_start); the stand-alone operator entry points build one from
+// their `tile` / `flags` arguments (include/mcgaze_hip.h, MCG_FLAG_*).
+struct ProfRec { hipEvent_t a, b; double flops; int cfg; int shape[3]; };
+struct Prof { ProfRec* recs = nullptr; int cap = 0, n = 0; };
+struct McgCtx {
+  int tile = -1;             // forced tile id of igemm_dma_kernel for Cout > 64 (bf16), -1 = heuristic (launch_typed)
+  bool staged = false;       // bf16: register-staged igemm_kernel instead of the LDS-DMA kernel (the first path; A/B and > 2 GiB fallback)
+  bool c64 = true;           // layer1's conv2 through conv3x3_c64.hpp
+  bool stem_fused = true;    // bf16 stem through stem_fused.hpp
+  bool chain = true;         // decoder row-block chains (chain.hpp)
+  Prof* prof = nullptr;      // armed: every contraction launch is bracketed by an event pair
+  static McgCtx from_flags(int tile, int flags) {
+    McgCtx c;
+    c.tile = tile > 0 ? tile : -1;
+    c.staged = (flags & MCG_FLAG_STAGED_GEMM) != 0;
+    c.c64 = !(flags & MCG_FLAG_NO_SPECIALISED);
+    c.stem_fused = !(flags & MCG_FLAG_NO_SPECIALISED);
+    c.chain = !(flags & MCG_FLAG_NO_SPECIALISED);
+    return c;
+  }
+};
+
 // Host-side launcher (igemm.hip).  Picks the tile shape from Cout / M.
-int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p, int groups);
+int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p, int groups, const McgCtx& ctx);
 // Convenience: y[M][Cout] = x[M][K] * w[Cout][K]^T (+bias)(+res)(relu), rows lda / ldy apart.
 int launch_linear(hipStream_t s, mcg_dtype dt, const void* x, long long lda, const void* w, const float* bias,
-                  const void* res, long long ldres, void* y, long long ldy, int M, int K, int Cout, int relu);
+                  const void* res, long long ldres, void* y, long long ldy, int M, int K, int Cout, int relu, const McgCtx& ctx);
 // Split-K linear: partial slabs [splitk][M][Cout] f32; returns the slice count through *splitk_out.
 int launch_linear_splitk(hipStream_t s, mcg_dtype dt, const void* x, long long lda, const void* w, float* partial,
-                         int M, int K, int Cout, int want_slices, int* splitk_out);
+                         int M, int K, int Cout, int want_slices, int* splitk_out, const McgCtx& ctx);
+// The C-ABI operators with an explicit context (the engine calls these; the extern "C" wrappers build the context from flags).
+int conv2d_ctx(hipStream_t s, mcg_dtype dt, const mcg_conv_desc* d, const McgCtx& ctx);
+int stem_forward_ctx(hipStream_t s, mcg_dtype dt, const float* img, const void* w_stem, const float* bias, void* y, int N, int H, int W,
+                     void* ws, size_t ws_bytes, const McgCtx& ctx);
+int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_COUNT], const void* roi_feat, const void* obj_in,
+                      const float* boxes_in, int N, int clip_length, void* obj_out, float* boxes_out, float* cls_out,
+                      const float stds[4], void* ws, size_t ws_bytes, const McgCtx& ctx);
+int gaze_head_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_GW_COUNT], const void* obj, int N, float* gaze_out,
+                  void* ws, size_t ws_bytes, const McgCtx& ctx);

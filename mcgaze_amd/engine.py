@@ -26,8 +26,9 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """The caller's current HIP stream on ``device`` (default: the current device)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _require_gpu():
@@ -60,9 +61,11 @@ def to_nchw(x_nhwc):
     return out
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual_mode=L.RES_NONE, x2=None, stride2=1, split=False):
+def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual_mode=L.RES_NONE, x2=None, stride2=1, split=False,
+           tile=0, flags=0):
     """x NHWC, w OHWI (same dtype), bias f32 -> NHWC.  mcg_conv2d.  With x2: w = [Cout,1,1,Cin+Cin2], x2 sampled at stride2.
-    split=True: the MCG_BF16X3 contraction -- x / residual f32, w given as f32 OHWI and split-packed here (packing.split_pack)."""
+    split=True: the MCG_BF16X3 contraction -- x / residual f32, w given as f32 OHWI and split-packed here (packing.split_pack).
+    tile / flags: mcg_conv_desc.tile (force a contraction tile) and MCG_FLAG_* (lib.FLAG_*)."""
     _require_gpu()
     lib = L.load()
     N, H, W, Cin = x.shape
@@ -79,20 +82,21 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual
                    N, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), residual_mode if residual is not None else L.RES_NONE,
                    residual.shape[1] if residual is not None else 0, residual.shape[2] if residual is not None else 0,
                    x2.data_ptr() if x2 is not None else None, Cin2, stride2, x2.shape[1] if x2 is not None else 0,
-                   x2.shape[2] if x2 is not None else 0)
+                   x2.shape[2] if x2 is not None else 0, tile, flags)
     L.check(lib.mcg_conv2d(_stream(), L.MCG_BF16X3 if split else _code(x.dtype), C.byref(d)), 'mcg_conv2d')
     return y
 
 
-def stem(img, w_stem, bias, dtype):
+def stem(img, w_stem, bias, dtype, flags=0, split=False):
     """img [N,3,H,W] f32 -> [N,H/4,W/4,64] NHWC.  mcg_stem_forward."""
     _require_gpu()
     lib = L.load()
     N, _, H, W = img.shape
-    ws = _ws(lib.mcg_stem_workspace_bytes(_code(dtype), N, H, W), img.device)
+    code = L.MCG_BF16X3 if split else _code(dtype)
+    ws = _ws(lib.mcg_stem_workspace_bytes(code, N, H, W), img.device)
     y = torch.empty(N, H // 4, W // 4, 64, dtype=dtype, device=img.device)
-    L.check(lib.mcg_stem_forward(_stream(), _code(dtype), _ptr(img.contiguous()), _ptr(w_stem), _ptr(bias), _ptr(y), N, H, W,
-                                 _ptr(ws), ws.numel()), 'mcg_stem_forward')
+    L.check(lib.mcg_stem_forward(_stream(), code, _ptr(img.contiguous()), _ptr(w_stem), _ptr(bias), _ptr(y), N, H, W,
+                                 _ptr(ws), ws.numel(), flags), 'mcg_stem_forward')
     return y
 
 
@@ -117,7 +121,7 @@ def _table(d, keys):
     return (C.c_void_p * len(keys))(*[d[k].data_ptr() for k in keys])
 
 
-def stage_forward(stage_w, roi_feat, obj, boxes, clip_length, stds=(0.5, 0.5, 1.0, 1.0), split=False):
+def stage_forward(stage_w, roi_feat, obj, boxes, clip_length, stds=(0.5, 0.5, 1.0, 1.0), split=False, flags=0):
     """One decoder stage.  roi_feat [R,49,256], obj [N,3,256], boxes [N,3,4] f32
     -> (obj' [N,3,256], boxes' [N,3,4], cls logits [N,3]).  mcg_stage_forward."""
     _require_gpu()
@@ -131,7 +135,7 @@ def stage_forward(stage_w, roi_feat, obj, boxes, clip_length, stds=(0.5, 0.5, 1.
     sd = (C.c_float * 4)(*stds)
     L.check(lib.mcg_stage_forward(_stream(), dt, _table(stage_w, L.STAGE_KEYS), _ptr(roi_feat.contiguous()), _ptr(obj.contiguous()),
                                   _ptr(boxes.contiguous().float()), N, clip_length, _ptr(obj_out), _ptr(boxes_out), _ptr(cls), sd,
-                                  _ptr(ws), ws.numel()), 'mcg_stage_forward')
+                                  _ptr(ws), ws.numel(), flags), 'mcg_stage_forward')
     return obj_out, boxes_out, cls
 
 
@@ -181,9 +185,33 @@ class HipEngine:
         mw.gaze_weights = C.cast(self._gaze_tab, C.POINTER(C.c_void_p))
         mw.bbox_stds = (C.c_float * 4)(*bbox_stds)
         self._handle = C.c_void_p()
-        L.check(self.lib.mcg_engine_create(C.byref(self._handle), C.byref(mw), self.code), 'mcg_engine_create')
+        with torch.cuda.device(self.device):   # the engine's side streams and events belong to THIS device
+            L.check(self.lib.mcg_engine_create(C.byref(self._handle), C.byref(mw), self.code), 'mcg_engine_create')
         self._ws = None
         self._ws_key = None
+
+    def set_option(self, name, value):
+        """mcg_engine_set_option: 'trunk_streams', 'max_range_frames', 'tile', 'staged_gemm', 'conv3x3_c64', 'stem_fused',
+        'decoder_chain', 'fused_bottleneck' (include/mcgaze_hip.h)."""
+        L.check(self.lib.mcg_engine_set_option(self._handle, name.encode(), int(value)), f'mcg_engine_set_option({name})')
+
+    def profile_start(self, capacity=4096):
+        L.check(self.lib.mcg_engine_profile_start(self._handle, capacity), 'mcg_engine_profile_start')
+
+    def profile_stop(self, capacity=4096):
+        """-> list of (ms, algorithmic flops, cfg id, (M, N, K)) per contraction launch recorded since profile_start."""
+        cnt = C.c_int()
+        ms = (C.c_float * capacity)(); fl = (C.c_double * capacity)(); cf = (C.c_int * capacity)(); sh = (C.c_int * (3 * capacity))()
+        L.check(self.lib.mcg_engine_profile_stop(self._handle, C.byref(cnt), ms, fl, cf, sh, capacity), 'mcg_engine_profile_stop')
+        return [(ms[i], fl[i], cf[i], (sh[3 * i], sh[3 * i + 1], sh[3 * i + 2])) for i in range(cnt.value)]
+
+    def backbone_only(self, img):
+        """BASELINE.json configs[1] measurement: the trunk up to C5 (mcg_bench_backbone_forward); returns nothing."""
+        self._check_img(img)
+        N, _, H, W = img.shape
+        with torch.cuda.device(self.device):
+            ws = self._workspace(N, H, W, 0)
+            L.check(self.lib.mcg_bench_backbone_forward(self._handle, _stream(self.device), _ptr(img), N, H, W, _ptr(ws), ws.numel()), 'mcg_bench_backbone_forward')
 
     def __del__(self):
         h = getattr(self, '_handle', None)
@@ -201,33 +229,63 @@ class HipEngine:
             self._ws_key = key
         return self._ws
 
+    def _check_img(self, img):
+        if not (img.is_cuda and img.device == self.device and img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4):
+            raise L.McgError(f'img must be a contiguous float32 [N,3,H,W] tensor on {self.device} (got {img.dtype} {tuple(img.shape)} on {img.device})')
+
     def backbone_fpn(self, img, chunk_frames=0):
         """img [N,3,H,W] f32 on the device -> [P2..P5] NHWC in the engine dtype."""
+        self._check_img(img)
         N, _, H, W = img.shape
-        ws = self._workspace(N, H, W, chunk_frames)
-        pyr = [torch.empty(N, (H // 4) >> i, (W // 4) >> i, 256, dtype=self.dtype, device=self.device) for i in range(4)]
-        tab = (C.c_void_p * 4)(*[p.data_ptr() for p in pyr])
-        L.check(self.lib.mcg_backbone_fpn_forward(self._handle, _stream(), _ptr(img), N, H, W, chunk_frames, tab, _ptr(ws), ws.numel()),
-                'mcg_backbone_fpn_forward')
+        with torch.cuda.device(self.device):
+            ws = self._workspace(N, H, W, chunk_frames)
+            pyr = [torch.empty(N, (H // 4) >> i, (W // 4) >> i, 256, dtype=self.dtype, device=self.device) for i in range(4)]
+            tab = (C.c_void_p * 4)(*[p.data_ptr() for p in pyr])
+            L.check(self.lib.mcg_backbone_fpn_forward(self._handle, _stream(self.device), _ptr(img), N, H, W, chunk_frames, tab, _ptr(ws), ws.numel()),
+                    'mcg_backbone_fpn_forward')
         return pyr
 
     def forward(self, img, clip_length, img_hw=None, chunk_frames=0, out=None):
         """img [N,3,H,W] f32 (device, contiguous), N = clips*clip_length.
         Returns dict(gaze [4,N,3], boxes [N,3,4], scores [N,3]) -- f32 device tensors."""
-        assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+        self._check_img(img)
         N, _, H, W = img.shape
-        ws = self._workspace(N, H, W, chunk_frames)
-        if out is None:
-            out = dict(gaze=torch.empty(4, N, 3, dtype=torch.float32, device=self.device),
-                       boxes=torch.empty(N, 3, 4, dtype=torch.float32, device=self.device),
-                       scores=torch.empty(N, 3, dtype=torch.float32, device=self.device))
-        hw = None
-        if img_hw is not None:
-            hw = torch.as_tensor(np.asarray(img_hw, dtype=np.int32).reshape(N, 2)).to(self.device) if not isinstance(img_hw, torch.Tensor) else img_hw
-        L.check(self.lib.mcg_clip_forward(self._handle, _stream(), _ptr(img), N, clip_length, H, W, _ptr(hw), chunk_frames,
-                                          _ptr(out['gaze']), _ptr(out['boxes']), _ptr(out['scores']), _ptr(ws), ws.numel()),
-                'mcg_clip_forward')
+        with torch.cuda.device(self.device):
+            ws = self._workspace(N, H, W, chunk_frames)
+            if out is None:
+                out = dict(gaze=torch.empty(4, N, 3, dtype=torch.float32, device=self.device),
+                           boxes=torch.empty(N, 3, 4, dtype=torch.float32, device=self.device),
+                           scores=torch.empty(N, 3, dtype=torch.float32, device=self.device))
+            hw = self.img_hw_tensor(img_hw, N)
+            L.check(self.lib.mcg_clip_forward(self._handle, _stream(self.device), _ptr(img), N, clip_length, H, W, _ptr(hw), chunk_frames,
+                                              _ptr(out['gaze']), _ptr(out['boxes']), _ptr(out['scores']), _ptr(ws), ws.numel()),
+                    'mcg_clip_forward')
         return out
+
+    def img_hw_tensor(self, img_hw, N):
+        """img_shape (h, w) per frame -> the device int32 [N,2] tensor the C-ABI takes (None stays None = every frame fills H x W)."""
+        if img_hw is None:
+            return None
+        if not isinstance(img_hw, torch.Tensor):
+            img_hw = torch.as_tensor(np.asarray(img_hw, dtype=np.int32).reshape(N, 2))
+        hw = img_hw.to(device=self.device, dtype=torch.int32).contiguous()
+        if hw.numel() != 2 * N:
+            raise L.McgError(f'img_hw must hold {N} (h, w) pairs, got {tuple(hw.shape)}')
+        return hw
+
+
+_PIPELINE_STREAMS = {}
+
+
+def pipeline_streams(device, decoder_priority=-1):
+    """The two streams of the batch pipeline, created ONCE per (device, priority) and shared by every runner of the process:
+    streams created later in a process's life land on hardware queues that serialise against earlier ones (engine.hip,
+    StreamPool), so a second runner with fresh streams loses the overlap the first one had."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), decoder_priority)
+    if key not in _PIPELINE_STREAMS:
+        _PIPELINE_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=decoder_priority))
+    return _PIPELINE_STREAMS[key]
 
 
 class PipelinedRunner:
@@ -237,11 +295,11 @@ class PipelinedRunner:
     Pyramids are double-buffered; trunks serialise on stream A, decoders on stream B, ordered by events.
     Every submitted batch is fully processed once ``flush()`` returns control to the caller's stream."""
 
-    def __init__(self, engine, num_frames, H, W, clip_length, chunk_frames=0):
+    def __init__(self, engine, num_frames, H, W, clip_length, chunk_frames=0, decoder_priority=-1):
         self.e, self.N, self.H, self.W, self.T, self.chunk = engine, num_frames, H, W, clip_length, chunk_frames
         dev, lib, h = engine.device, engine.lib, engine._handle
         # the decoder's short launches get the high-priority queue so they slot in between the trunk's long kernels
-        self.sa, self.sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=int(os.environ.get('MCG_DECODER_PRIORITY', '-1')))
+        self.sa, self.sb = pipeline_streams(dev, decoder_priority)
         self.pyr = [[torch.empty(num_frames, (H // 4) >> i, (W // 4) >> i, 256, dtype=engine.dtype, device=dev) for i in range(4)] for _ in range(2)]
         self.tabs = [(C.c_void_p * 4)(*[p.data_ptr() for p in lvl]) for lvl in self.pyr]
         self.trunk_ws = _ws(lib.mcg_trunk_workspace_bytes(h, num_frames, H, W, chunk_frames), dev)
@@ -249,11 +307,19 @@ class PipelinedRunner:
         self.trunk_done = [torch.cuda.Event() for _ in range(2)]
         self.dec_done = [torch.cuda.Event() for _ in range(2)]
         self.used = [False, False]
+        self._hw_keep = [None, None]
         self.k = 0
 
     def submit(self, img, out, img_hw=None):
         """Enqueue one batch: img [N,3,H,W] f32 (must stay valid until its trunk ran), out = dict(gaze, boxes, scores)."""
+        with torch.cuda.device(self.e.device):
+            return self._submit(img, out, img_hw)
+
+    def _submit(self, img, out, img_hw):
         e, lib, slot = self.e, self.e.lib, self.k & 1
+        e._check_img(img)
+        img_hw = e.img_hw_tensor(img_hw, self.N)
+        self._hw_keep[slot] = img_hw            # stays alive until the slot's decoder has run
         cur = torch.cuda.current_stream(e.device)
         self.sa.wait_stream(cur)                       # input produced on the caller's stream
         if self.used[slot]:

@@ -13,6 +13,7 @@ MCG_OK = 0
 MCG_F32, MCG_BF16, MCG_BF16X3 = 0, 1, 2
 ABI_VERSION = 3
 RES_NONE, RES_ADD, RES_UPSAMPLE_ADD = 0, 1, 2
+FLAG_STAGED_GEMM, FLAG_NO_SPECIALISED = 1, 2
 
 # enum order of include/mcgaze_hip.h
 STAGE_KEYS = [
@@ -28,7 +29,8 @@ EXPORTS = ['mcg_abi_version', 'mcg_last_error', 'mcg_device_info', 'mcg_nchw_to_
            'mcg_stem_workspace_bytes', 'mcg_stem_forward', 'mcg_roi_align', 'mcg_stage_workspace_bytes', 'mcg_stage_forward',
            'mcg_gaze_head_workspace_bytes', 'mcg_gaze_head', 'mcg_engine_create', 'mcg_engine_destroy',
            'mcg_engine_workspace_bytes', 'mcg_trunk_workspace_bytes', 'mcg_decoder_workspace_bytes', 'mcg_backbone_fpn_forward',
-           'mcg_decoder_forward', 'mcg_clip_forward', 'mcg_preprocess_frames', 'mcg_profile_start', 'mcg_profile_stop']
+           'mcg_decoder_forward', 'mcg_clip_forward', 'mcg_preprocess_frames', 'mcg_engine_set_option', 'mcg_engine_profile_start',
+           'mcg_engine_profile_stop', 'mcg_bench_backbone_forward']
 
 
 class ConvDesc(C.Structure):
@@ -36,7 +38,7 @@ class ConvDesc(C.Structure):
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('KH', C.c_int),
                 ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('relu', C.c_int), ('residual_mode', C.c_int),
                 ('Hr', C.c_int), ('Wr', C.c_int), ('x2', C.c_void_p), ('Cin2', C.c_int), ('stride2', C.c_int), ('H2', C.c_int),
-                ('W2', C.c_int)]
+                ('W2', C.c_int), ('tile', C.c_int), ('flags', C.c_int)]
 
 
 class ConvWeights(C.Structure):
@@ -81,11 +83,11 @@ def load():
     lib.mcg_conv2d.argtypes = [vp, i, C.POINTER(ConvDesc)]
     lib.mcg_stem_workspace_bytes.restype = sz
     lib.mcg_stem_workspace_bytes.argtypes = [i, i, i, i]
-    lib.mcg_stem_forward.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, vp, sz]
+    lib.mcg_stem_forward.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, vp, sz, i]
     lib.mcg_roi_align.argtypes = [vp, i, C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(i), i, vp, i, i, vp, vp]
     lib.mcg_stage_workspace_bytes.restype = sz
     lib.mcg_stage_workspace_bytes.argtypes = [i, i]
-    lib.mcg_stage_forward.argtypes = [vp, i, C.POINTER(vp), vp, vp, vp, i, i, vp, vp, vp, C.POINTER(C.c_float), vp, sz]
+    lib.mcg_stage_forward.argtypes = [vp, i, C.POINTER(vp), vp, vp, vp, i, i, vp, vp, vp, C.POINTER(C.c_float), vp, sz, i]
     lib.mcg_gaze_head_workspace_bytes.restype = sz
     lib.mcg_gaze_head_workspace_bytes.argtypes = [i, i]
     lib.mcg_gaze_head.argtypes = [vp, i, C.POINTER(vp), vp, i, vp, vp, sz]
@@ -102,8 +104,10 @@ def load():
     lib.mcg_backbone_fpn_forward.argtypes = [vp, vp, vp, i, i, i, i, C.POINTER(vp), vp, sz]
     lib.mcg_clip_forward.argtypes = [vp, vp, vp, i, i, i, i, vp, i, vp, vp, vp, vp, sz]
     lib.mcg_preprocess_frames.argtypes = [vp, vp, i, vp, i, i, C.POINTER(C.c_float), C.POINTER(C.c_float), i]
-    lib.mcg_profile_start.argtypes = [i]
-    lib.mcg_profile_stop.argtypes = [C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i), C.POINTER(i), i]
+    lib.mcg_engine_set_option.argtypes = [vp, C.c_char_p, i]
+    lib.mcg_engine_profile_start.argtypes = [vp, i]
+    lib.mcg_engine_profile_stop.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i), C.POINTER(i), i]
+    lib.mcg_bench_backbone_forward.argtypes = [vp, vp, vp, i, i, i, vp, sz]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('mcg_abi_version',):

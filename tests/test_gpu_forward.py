@@ -19,7 +19,10 @@ from oracle import mcgaze_oracle as orc
 pytestmark = pytest.mark.gpu
 
 F32_TOL = 1e-3    # north_star
-BF16_TOL = 3e-1  # rad, loose bound on RANDOM-weight nets (no trained checkpoint here); the measured value is printed
+# bf16 THROUGHPUT engine, RANDOM-weight nets: bounds = the largest measured deviation x 1.3 (it is NOT within north_star's 1e-3; the
+# bf16x3 engine is).  Goldens (224x224 clips): 0.164 rad measured; unusual shapes (64x64 frames, 101-frame clip): 0.244 rad measured.
+BF16_TOL = 0.215
+BF16_TOL_UNUSUAL = 0.32
 CASES = ['clip224', 'clip_nonsquare', 'batch2', 'clip_t5']
 KEYS = ('gaze_score', 'face_gaze_score', 'eyes_gaze_score', 'head_gaze_score')
 
@@ -198,38 +201,150 @@ def test_fp32_engine_matches_oracle_on_unusual_shapes(engines, B, T, H, W):
             assert d < F32_TOL, (precision, k, d)
         np.testing.assert_allclose(out['boxes'].cpu().numpy(), want_det[..., :4].numpy(), atol=5e-2, rtol=1e-4)
     bf = engines['bf16'].forward(torch.from_numpy(img).to('cuda:0'), T)
-    assert torch.isfinite(bf['gaze']).all() and (orc.yaw_pitch(bf['gaze'][0].cpu()) - orc.yaw_pitch(want_gaze['gaze_score'])).abs().max().item() < BF16_TOL
+    assert torch.isfinite(bf['gaze']).all() and (orc.yaw_pitch(bf['gaze'][0].cpu()) - orc.yaw_pitch(want_gaze['gaze_score'])).abs().max().item() < BF16_TOL_UNUSUAL
 
 
-def test_frame_range_cap_and_stream_split_do_not_change_results(engines, monkeypatch):
+def test_frame_range_cap_and_stream_split_do_not_change_results(engines):
     """The trunk runs as concurrent frame ranges, capped so that no activation outgrows the 2 GiB descriptor window; a batch
     beyond k capped ranges takes several rounds.  Forcing a tiny cap (many rounds), one stream, or four must all give the bits
-    of the default."""
+    of the default (options through mcg_engine_set_option)."""
     T, B = 7, 40
     img = torch.from_numpy(synth.make_clips(77, B, T, 64, 96)).to('cuda:0')
     e = engines['bf16']
     ref = {k: v.clone() for k, v in e.forward(img, T).items()}
-    for env in (dict(MCG_MAX_RANGE_FRAMES='40'), dict(MCG_TRUNK_STREAMS='1'), dict(MCG_TRUNK_STREAMS='4'), dict(MCG_TRUNK_STREAMS='3', MCG_MAX_RANGE_FRAMES='57')):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        out = e.forward(img, T)
-        torch.cuda.synchronize()
-        for k in ref:
-            assert torch.equal(out[k], ref[k]), (env, k)
-        for k in env:
-            monkeypatch.delenv(k)
+    try:
+        for opts in (dict(max_range_frames=40), dict(trunk_streams=1), dict(trunk_streams=4), dict(trunk_streams=3, max_range_frames=57)):
+            e.set_option('trunk_streams', 2); e.set_option('max_range_frames', 0)
+            for k, v in opts.items():
+                e.set_option(k, v)
+            out = e.forward(img, T)
+            torch.cuda.synchronize()
+            for k in ref:
+                assert torch.equal(out[k], ref[k]), (opts, k)
+    finally:
+        e.set_option('trunk_streams', 2); e.set_option('max_range_frames', 0)
 
 
-def test_fused_bottleneck_is_bit_identical(engines, monkeypatch):
+def test_fused_bottleneck_is_bit_identical(engines):
     """bottleneck_fused.hpp (layer1's identity blocks as one kernel each) against the three launches it replaces: the pyramid the
     trunk produces must not change by a bit -- on a frame size that is not a multiple of its 8 x 28 tile as well."""
     e = engines['bf16']
     for shape in ((3, 224, 224), (2, 96, 160)):
         img = torch.from_numpy(synth.make_clips(31, 1, *shape)).to('cuda:0')
-        monkeypatch.setenv('MCG_FUSED_BLOCK', '0')
+        e.set_option('fused_bottleneck', 0)
         ref = [p.clone() for p in e.backbone_fpn(img)]
-        monkeypatch.setenv('MCG_FUSED_BLOCK', '1')
+        e.set_option('fused_bottleneck', 1)
         out = e.backbone_fpn(img)
         torch.cuda.synchronize()
+        e.set_option('fused_bottleneck', 0)
         for a, b in zip(ref, out):
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), shape
+
+
+# Per-stage deviation of the bf16 THROUGHPUT engine from the reference goldens (random weights), as a fraction of each tensor's
+# scale.  What this test established: bf16 rounding alone keeps the query features within ~1 % of scale and the boxes within ~1.5 px
+# per stage; the engine's 0.03-0.16 rad gaze deviation comes from a DISCONTINUITY of the model itself -- a box whose sqrt(area) sits
+# next to a pyramid-level boundary (56 * 2^k px, single_level_roi_extractor.py:51-54) is routed to a different FPN level after a
+# one-pixel perturbation, and the stage's features then differ by ~50 % of scale.  So: smooth bounds (measured x 1.3) hold for every
+# stage up to the first routing flip, the error may not grow faster than rounding does, and a jump is only accepted where a flip
+# explains it.
+BF16_SMOOTH_OBJ_BOUND = 0.02     # measured 0.010 / 0.013 on stages 0 / 1 of clip224
+BF16_SMOOTH_BOX_BOUND = 2.5      # px; measured 1.0 / 1.55
+BF16_STAGE_GROWTH = 2.0          # a smooth stage may be at most this many times worse than the one before
+
+
+@pytest.mark.parametrize('name', ['clip224', 'batch2'])
+def test_bf16_error_growth_per_stage(golden_dir, engines, name):
+    from mcgaze_amd import engine as E
+    g, img, B, T, ishape = load_case(golden_dir, name)
+    e = engines['bf16']
+    pyr = e.backbone_fpn(torch.from_numpy(img).to('cuda:0'))
+    for i, p in enumerate(pyr):      # pyramid samples the reference recorded
+        flat = p.permute(0, 3, 1, 2).reshape(-1).float().cpu()
+        err = float((flat[torch.from_numpy(g[f'fpn{i}_idx'])] - torch.from_numpy(g[f'fpn{i}_val'])).abs().max() / float(g[f'fpn{i}_absmean']))
+        print(f'{name} bf16 P{i + 2}: max sample error = {err:.3f} of the level\'s mean |value|')
+        assert err < 0.045, (i, err)          # measured 0.024 .. 0.032
+    N = B * T
+    boxes = torch.from_numpy(g['init_boxes']).to('cuda:0')
+    ref_boxes_in = torch.from_numpy(g['init_boxes'])
+    obj = e.weights.init_feats[None].expand(N, 3, 256).contiguous()
+    prev, flipped = None, False
+    for s in range(4):
+        roi, lv = E.roi_align(pyr, boxes)
+        flips = int((lv.cpu().long() != orc.map_roi_levels(ref_boxes_in.reshape(-1, 4))).sum())
+        flipped = flipped or flips > 0
+        obj, boxes, cls = E.stage_forward(e.weights.stages[s], roi, obj, boxes, T)
+        torch.cuda.synchronize()
+        want = torch.from_numpy(g['stage_obj'][s])
+        err = float((obj.float().cpu() - want).abs().max() / want.abs().max())
+        berr = float((boxes.cpu() - torch.from_numpy(g['stage_boxes'][s])).abs().max())
+        print(f'{name} bf16 stage {s}: obj error = {err:.4f} of scale, boxes max |d| = {berr:.2f} px, level-routing flips so far: {flips}{" (discontinuity)" if flipped else ""}')
+        assert np.isfinite(err) and np.isfinite(berr)
+        if not flipped:
+            assert err < BF16_SMOOTH_OBJ_BOUND and berr < BF16_SMOOTH_BOX_BOUND, (s, err, berr)
+            if prev is not None:
+                assert err < BF16_STAGE_GROWTH * prev, (s, err, prev)
+            prev = err
+        ref_boxes_in = torch.from_numpy(g['stage_boxes'][s])
+    # the parity-grade engine follows the reference through every stage, routing included
+    e3 = engines['bf16x3']
+    pyr3 = e3.backbone_fpn(torch.from_numpy(img).to('cuda:0'))
+    boxes3, obj3 = torch.from_numpy(g['init_boxes']).to('cuda:0'), e3.weights.init_feats[None].expand(N, 3, 256).contiguous()
+    ref_boxes_in = torch.from_numpy(g['init_boxes'])
+    for s in range(4):
+        roi, lv = E.roi_align(pyr3, boxes3)
+        assert int((lv.cpu().long() != orc.map_roi_levels(ref_boxes_in.reshape(-1, 4))).sum()) == 0, s
+        obj3, boxes3, _ = E.stage_forward(e3.weights.stages[s], roi, obj3, boxes3, T, split=True)
+        torch.cuda.synchronize()
+        want = torch.from_numpy(g['stage_obj'][s])
+        err = float((obj3.cpu() - want).abs().max() / want.abs().max())
+        print(f'{name} bf16x3 stage {s}: obj error = {err:.2e} of scale')
+        assert err < 2e-4, (s, err)
+        ref_boxes_in = torch.from_numpy(g['stage_boxes'][s])
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
+def test_bench_schedule_is_bitwise_equal_to_per_clip_calls(precision):
+    """Exactly what bench.py times at BASELINE.json configs[2]: 64 clips x 7 x 3 x 224 x 224 (448 frames), chunk_frames = 0 ->
+    two concurrent frame ranges on probed side streams, the two-deep PipelinedRunner, and the result exchange on its own stream
+    through a (single-rank) RCCL group -- driven through bench.Leg itself.  Every clip of the timed schedule's output must
+    equal, bit for bit, a separate single-clip call of the same engine, and bench's own `verify()` must agree."""
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    argv, sys.argv = sys.argv, ['bench.py']
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = argv
+    dev = torch.device('cuda', 0)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29561')
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        B, T = 64, 7
+        img = torch.from_numpy(synth.make_clips(3, B, T)).to(dev)
+        leg = bench.Leg(a, precision, dev, 1, 0, dist, img, B, T)
+        assert leg.runner is not None and leg.comm is not None
+        for _ in range(5):
+            leg.step()
+        leg.drain()
+        torch.cuda.synchronize()
+        assert leg.verify() is True
+        for slot in (0, 1):
+            out = leg.outs[slot]
+            merged = leg.gathers[slot].all_single()      # what the exchange delivered
+            assert torch.equal(merged, leg.gathers[slot].local)
+            for b in range(0, B, 3):
+                one = leg.eng.forward(img[b * T:(b + 1) * T].contiguous(), T)
+                torch.cuda.synchronize()
+                assert torch.equal(one['gaze'], out['gaze'][:, b * T:(b + 1) * T]), (slot, b)
+                assert torch.equal(one['boxes'], out['boxes'][b * T:(b + 1) * T]), (slot, b)
+                assert torch.equal(one['scores'], out['scores'][b * T:(b + 1) * T]), (slot, b)
+    finally:
+        if own_group:
+            dist.destroy_process_group()

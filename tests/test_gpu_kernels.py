@@ -256,7 +256,7 @@ def test_stem(eng, sd, dtype):
 
 
 @pytest.mark.parametrize('shape', [(21, 14, 14, 256, 256, 3, 1, 1), (3, 28, 28, 128, 512, 1, 1, 0), (2, 30, 22, 64, 256, 3, 2, 1)])
-def test_every_dma_tile_is_bit_identical(eng, shape, monkeypatch):
+def test_every_dma_tile_is_bit_identical(eng, shape):
     """All tile shapes of igemm_dma_kernel walk K in the same order, so their outputs must agree bit for bit -- which also
     catches tiling bugs a tolerance hides (a ragged last epilogue pass once wrote stale rows into the next tile)."""
     n, h, w, cin, cout, k, stride, pad = shape
@@ -267,9 +267,10 @@ def test_every_dma_tile_is_bit_identical(eng, shape, monkeypatch):
     ho = (h + 2 * pad - k) // stride + 1
     r = torch.randn(n, ho, (w + 2 * pad - k) // stride + 1, cout, generator=g).to(torch.bfloat16).to('cuda:0')
     outs = {}
-    for tile in (9, 0, 1, 2, 3, 8, 10, 11, 12, 13, 14, 15, 16, 21, 22):
-        monkeypatch.setenv('MCG_TILE', str(tile))
-        outs[tile] = eng.conv2d(x, wt, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1).clone()
+    for tile in (9, 11, 12, 14, 15):   # every tile the heuristic can choose (igemm.hip), forced through mcg_conv_desc.tile
+        outs[tile] = eng.conv2d(x, wt, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1, tile=tile).clone()
+    from mcgaze_amd import lib as L
+    outs['staged'] = eng.conv2d(x, wt, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1, flags=L.FLAG_STAGED_GEMM).clone()
     torch.cuda.synchronize()
     for tile, y in outs.items():
         assert torch.equal(y.view(torch.int16), outs[9].view(torch.int16)), tile
@@ -277,7 +278,7 @@ def test_every_dma_tile_is_bit_identical(eng, shape, monkeypatch):
 
 @pytest.mark.parametrize('shape', [(3, 56, 56), (2, 28, 84), (1, 9, 5), (2, 80, 112)])
 @pytest.mark.parametrize('relu', [True, False])
-def test_conv3x3_c64_is_bit_identical_to_the_generic_kernel(eng, shape, relu, monkeypatch):
+def test_conv3x3_c64_is_bit_identical_to_the_generic_kernel(eng, shape, relu):
     """conv3x3_c64.hpp (layer1's conv2: input window staged once, taps by address) keeps the generic kernel's K order: same bits,
     incl. maps that are not a multiple of its 8 x 28 tile and maps smaller than one tile."""
     n, h, w = shape
@@ -285,25 +286,23 @@ def test_conv3x3_c64_is_bit_identical_to_the_generic_kernel(eng, shape, relu, mo
     x = torch.randn(n, h, w, 64, generator=g).to(torch.bfloat16).to('cuda:0')
     wt = (torch.randn(64, 3, 3, 64, generator=g) / 24.0).to(torch.bfloat16).to('cuda:0')
     b = torch.randn(64, generator=g).to('cuda:0')
-    monkeypatch.setenv('MCG_C64', '0')
-    a = eng.conv2d(x, wt, b, stride=1, pad=1, relu=relu).clone()
-    monkeypatch.setenv('MCG_C64', '1')
+    from mcgaze_amd import lib as L
+    a = eng.conv2d(x, wt, b, stride=1, pad=1, relu=relu, flags=L.FLAG_NO_SPECIALISED).clone()
     c = eng.conv2d(x, wt, b, stride=1, pad=1, relu=relu)
     torch.cuda.synchronize()
     assert torch.equal(a.view(torch.int16), c.view(torch.int16))
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 96), (3, 224, 224), (1, 320, 448), (2, 36, 52)])
-def test_fused_stem_is_bit_identical_to_the_three_kernel_path(eng, sd, shape, monkeypatch):
+def test_fused_stem_is_bit_identical_to_the_three_kernel_path(eng, sd, shape):
     """stem_fused.hpp keeps the unfused path's packing and K order, so not even rounding may differ -- incl. sizes whose
     pooled map is not a multiple of the 8x8 tile (36x52 -> 9x13)."""
     from mcgaze_amd.packing import PackedWeights
     pw = PackedWeights(sd, dtype=torch.bfloat16)
     n, h, w = shape
     img = torch.from_numpy(synth.make_clips(7, 1, n, h, w)).to('cuda:0')
-    monkeypatch.setenv('MCG_STEM_FUSED', '0')
-    a = eng.stem(img, pw.stem['w'], pw.stem['bias'], torch.bfloat16).clone()
-    monkeypatch.setenv('MCG_STEM_FUSED', '1')
+    from mcgaze_amd import lib as L
+    a = eng.stem(img, pw.stem['w'], pw.stem['bias'], torch.bfloat16, flags=L.FLAG_NO_SPECIALISED).clone()
     b = eng.stem(img, pw.stem['w'], pw.stem['bias'], torch.bfloat16)
     torch.cuda.synchronize()
     assert a.shape == b.shape == (n, h // 4, w // 4, 64)
@@ -355,7 +354,7 @@ def test_decoder_stage(eng, sd, dtype, B, T):
 
 
 @pytest.mark.parametrize('B,T', [(1, 7), (5, 3), (11, 1)])
-def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T, monkeypatch):
+def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T):
     """chain.hpp (towers and attention out-projection + LayerNorm as single launches) keeps the K order, the bf16 rounding points
     and the LayerNorm reduction order of the launch sequence it replaces -- incl. row counts that are not a multiple of its 32-row
     block."""
@@ -367,9 +366,9 @@ def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T, monkeypatch):
     obj = torch.randn(N, 3, 256, generator=g).to(torch.bfloat16).to('cuda:0')
     boxes = (torch.tensor([[20., 30., 200., 210.], [60., 50., 160., 150.], [90., 60., 130., 100.]])[None].repeat(N, 1, 1) + torch.randn(N, 3, 4, generator=g)).to('cuda:0')
     outs = {}
-    for mode in ('0', '1'):
-        monkeypatch.setenv('MCG_CHAIN', mode)
-        outs[mode] = [t.clone() for t in eng.stage_forward(pw.stages[1], roi, obj, boxes, T)]
+    from mcgaze_amd import lib as L
+    for mode, flags in (('0', L.FLAG_NO_SPECIALISED), ('1', 0)):
+        outs[mode] = [t.clone() for t in eng.stage_forward(pw.stages[1], roi, obj, boxes, T, flags=flags)]
     torch.cuda.synchronize()
     for a, b, name in zip(outs['0'], outs['1'], ('obj', 'boxes', 'cls')):
         assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), name

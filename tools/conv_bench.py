@@ -1,4 +1,5 @@
-"""GPU tool: time one conv shape through mcg_conv2d.  usage: conv_bench.py N H W Cin Cout k stride pad [iters] [residual]"""
+"""GPU tool: time one conv shape through mcg_conv2d.
+usage: conv_bench.py N H W Cin Cout k stride pad [iters] [residual] [tile] [precision bf16|bf16x3|fp32] [data randn|zeros|relu|small]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,9 +7,12 @@ from mcgaze_amd import engine as E
 N, H, W, Cin, Cout, k, stride, pad = [int(v) for v in sys.argv[1:9]]
 iters = int(sys.argv[9]) if len(sys.argv) > 9 else 50
 res = int(sys.argv[10]) if len(sys.argv) > 10 else 0
-dt = torch.bfloat16
+tile = int(sys.argv[11]) if len(sys.argv) > 11 else 0
+prec = sys.argv[12] if len(sys.argv) > 12 else 'bf16'
+mode = sys.argv[13] if len(sys.argv) > 13 else 'randn'   # the rate depends on the operand bits: the kernel sits on the package power cap
+dt = torch.bfloat16 if prec == 'bf16' else torch.float32
+split = prec == 'bf16x3'
 x = torch.randn(N, H, W, Cin, device='cuda')
-mode = os.environ.get('MCG_BENCH_DATA', 'randn')   # the rate depends on the operand bits: the kernel sits on the package power cap
 if mode == 'zeros': x.zero_()
 elif mode == 'relu': x.relu_()
 elif mode == 'small': x.mul_(1e-3)
@@ -18,12 +22,12 @@ b = torch.randn(Cout, device='cuda')
 Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
 r = torch.randn(N, Ho, Wo, Cout, device='cuda').to(dt) if res else None
 for _ in range(60):
-    y = E.conv2d(x, w, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1 if res else 0)
+    y = E.conv2d(x, w, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1 if res else 0, tile=tile, split=split)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(iters):
-    y = E.conv2d(x, w, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1 if res else 0)
+    y = E.conv2d(x, w, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1 if res else 0, tile=tile, split=split)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / iters * 1e3
 fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
-print(f'conv N={N} {H}x{W} {Cin}->{Cout} k{k} s{stride}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TF/s  (MCG_TILE={os.environ.get("MCG_TILE", "auto")}, data={mode})')
+print(f'conv N={N} {H}x{W} {Cin}->{Cout} k{k} s{stride}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TF/s  (tile={tile or "auto"}, {prec}, data={mode})')

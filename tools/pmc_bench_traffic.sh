@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  MCG_TRUNK_STREAMS=1 timeout 240 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o $C --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel-events none --pipeline 0 > $OUT/$C.log 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o $C --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel-events none --pipeline 0 --trunk-streams 1 --parity-engine ${PARITY:-none} --latency 0 --precision ${PRECISION:-bf16} > $OUT/$C.log 2>&1
   echo "$C pass rc=$?"
 done
 cd $R
@@ -21,6 +21,9 @@ res = {}
 for k, d in agg.items():
     m = re.search(r'igemm_dma_kernel<unsigned short, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)', k)
     name = f'igemm_dma_kernel<bf16,{",".join(m.groups())}>' if m else k
+    m = re.search(r'igemm_dma_kernel<float, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 1>', k)
+    if m:
+        name = f'igemm_dma_kernel<float,{",".join(m.groups())},x3>'
     fetch = sum(d['FETCH_SIZE']) / max(len(d['FETCH_SIZE']), 1) * 1024 * 2   # KiB units; x2: gfx950 FETCH_SIZE counts 128-B requests as 64 B
     write = sum(d['WRITE_SIZE']) / max(len(d['WRITE_SIZE']), 1) * 1024
     e = res.setdefault(name, {'fetch_bytes_per_launch': 0, 'write_bytes_per_launch': 0, 'launches_sampled': 0})

@@ -4,7 +4,7 @@
 #        tools/power_probe.sh bench          -- the whole path (bench.py, 600 steps)
 R=$GRAFT_REPO_ROOT
 if [ "${1:-conv}" = bench ]; then python $R/bench.py --steps 600 --warmup 5 --cpu-seconds 0 > /tmp/load.log 2>&1 &
-else MCG_TILE=${2:-14} python $R/tools/conv_bench.py 448 56 56 256 256 3 1 1 4000 > /tmp/load.log 2>&1 & fi
+else python $R/tools/conv_bench.py 448 56 56 256 256 3 1 1 4000 0 ${2:-14} > /tmp/load.log 2>&1 & fi
 PID=$!
 sleep ${SLEEP:-4}
 for i in 1 2 3 4 5; do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | sed 's/.*: //' | tr '\n' ' '; echo; sleep 0.5; done
