@@ -55,3 +55,37 @@ class ResultGather:
         parts = [self.rank_views(r) for r in range(self.world)]
         return dict(gaze=torch.cat([p['gaze'] for p in parts], dim=1), boxes=torch.cat([p['boxes'] for p in parts]),
                     scores=torch.cat([p['scores'] for p in parts]))
+
+
+# ------------------------------------------------------------------------------------ dataset runs (tools/test_gaze360_gaze.py)
+def shard_videos(videos, world, rank):
+    """Whole videos per rank (the overlap merge needs all windows of a video on one rank), balanced by frame
+    count: longest video first onto the least-loaded rank.  Returns this rank's video indices in annotation order."""
+    order = sorted(range(len(videos)), key=lambda i: -len(videos[i]['file_names']))
+    load, mine = [0] * world, []
+    for i in order:
+        r = min(range(world), key=lambda k: load[k])
+        load[r] += len(videos[i]['file_names'])
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
+
+
+def gather_records(idx, recs, num_videos, group=None):
+    """The dataset run's only exchange (the reference's only gather is mmdet/apis/test.py:179-209, collect_results): every rank
+    contributes its (video index, record) pairs; every rank gets the records of ALL videos back in annotation order.  Raises if a
+    video is missing or was produced twice."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    parts = [None] * world
+    dist.all_gather_object(parts, list(zip(idx, recs)), group=group)
+    merged = {}
+    for part in parts:
+        for i, rec in part:
+            if i in merged:
+                raise RuntimeError(f'video {i} was processed by more than one rank')
+            merged[i] = rec
+    missing = [i for i in range(num_videos) if i not in merged]
+    if missing:
+        raise RuntimeError(f'no rank processed videos {missing[:8]}')
+    return [merged[i] for i in range(num_videos)]

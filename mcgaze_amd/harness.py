@@ -88,34 +88,48 @@ def result_file_name(config_path, json_path):
 
 
 def _run_windows(engine, ids, plans, get_window, batch_clips, person_threshold):
-    """Core of run_videos / run_annotation: windows with the same (T, H, W) are packed into batches of up to ``batch_clips``
-    clips and run with the batched semantics (N = B*T frames, clip_length = T); results are merged per video on the device.
+    """Core of run_videos / run_annotation, STREAMING: windows are visited in (video, window) order -- the reference's order, so the
+    crop RNG draws inside ``get_window`` fall where upstream's do -- and dropped into per-(T, H, W) buckets; a bucket runs through
+    the engine (batched semantics: N = B*T frames, clip_length = T) as soon as it holds ``batch_clips`` clips and its inputs are
+    released; a video is merged and turned into its record as soon as its last window has come back.  Device memory is bounded by
+    ``batch_clips`` clips per distinct window shape, not by the size of the dataset.
     get_window(vi, wi) -> (frames [T,3,H,W] f32, img_hw [T,2] int or None, scale [T,4] f32 or None)."""
     dev = engine.device
-    jobs = {}
+    buckets = {}                                       # (T, H, W) -> list of (vi, wi, frames, hw, scale)
+    outputs = [[None] * len(p) for p in plans]
+    pending = [len(p) for p in plans]
+    records = [None] * len(plans)
+
+    def flush(key):
+        items = buckets.pop(key, [])
+        if not items:
+            return
+        T = key[0]
+        x = torch.cat([it[2] for it in items]).to(dev, torch.float32).contiguous()
+        hw = None if items[0][3] is None else torch.cat([torch.as_tensor(it[3], dtype=torch.int32).reshape(-1, 2) for it in items]).numpy()
+        out = engine.forward(x, T, img_hw=hw)
+        boxes = out['boxes']
+        if items[0][4] is not None:   # rescale=True: every frame's boxes by its own scale_factor (multiclue_gaze_roi_head.py:360-363)
+            boxes = boxes / torch.cat([torch.as_tensor(it[4], dtype=torch.float32) for it in items]).to(dev)[:, None, :]
+        det = torch.cat([boxes, out['scores'][..., None]], dim=-1)
+        for bi, (vi, wi, _, _, _) in enumerate(items):
+            sl = slice(bi * T, (bi + 1) * T)
+            outputs[vi][wi] = (det[sl].clone(), out['gaze'][0, sl].clone(), out['gaze'][1:, sl].permute(1, 0, 2).clone())
+            pending[vi] -= 1
+            if pending[vi] == 0:                       # all windows of the video are back: merge, record, release
+                records[vi] = video_record(ids[vi], *merge_video(plans[vi], outputs[vi], person_threshold))
+                outputs[vi] = None
+
     for vi, plan in enumerate(plans):
         for wi in range(len(plan)):
-            jobs.setdefault((plan[wi][1] - plan[wi][0], vi, wi), None)
-    windows = {k: get_window(k[1], k[2]) for k in jobs}          # video order, window order: the reference's RNG order
-    groups = {}
-    for (T, vi, wi), (x, hw, sc) in windows.items():
-        groups.setdefault((T, x.shape[-2], x.shape[-1]), []).append((vi, wi))
-    outputs = [[None] * len(p) for p in plans]
-    for (T, H, W), items in sorted(groups.items()):
-        for s in range(0, len(items), batch_clips):
-            chunk = items[s:s + batch_clips]
-            parts = [windows[(T, vi, wi)] for vi, wi in chunk]
-            x = torch.cat([p[0] for p in parts]).to(dev, torch.float32).contiguous()
-            hw = None if parts[0][1] is None else torch.cat([torch.as_tensor(p[1], dtype=torch.int32) for p in parts]).numpy()
-            out = engine.forward(x, T, img_hw=hw)
-            boxes = out['boxes']
-            if parts[0][2] is not None:   # rescale=True: every frame's boxes by its own scale_factor (multiclue_gaze_roi_head.py:360-363)
-                boxes = boxes / torch.cat([torch.as_tensor(p[2], dtype=torch.float32) for p in parts]).to(dev)[:, None, :]
-            det = torch.cat([boxes, out['scores'][..., None]], dim=-1)
-            for bi, (vi, wi) in enumerate(chunk):
-                sl = slice(bi * T, (bi + 1) * T)
-                outputs[vi][wi] = (det[sl].clone(), out['gaze'][0, sl].clone(), out['gaze'][1:, sl].permute(1, 0, 2).clone())
-    return [video_record(ids[vi], *merge_video(plans[vi], outputs[vi], person_threshold)) for vi in range(len(plans))]
+            x, hw, sc = get_window(vi, wi)
+            key = (plan[wi][1] - plan[wi][0], x.shape[-2], x.shape[-1])
+            buckets.setdefault(key, []).append((vi, wi, x, hw, sc))
+            if len(buckets[key]) >= batch_clips:
+                flush(key)
+    for key in sorted(buckets):
+        flush(key)
+    return records
 
 
 def run_videos(engine, videos, clip_len=7, stride=4, batch_clips=64, scale_factor=None, person_threshold=0.5):

@@ -58,3 +58,67 @@ def test_views_alias_the_fused_buffer():
     v = g.local_views()
     v['scores'].fill_(2.0)
     assert g.local.numel() == FLOATS_PER_FRAME * 5 and float(g.local[-1]) == 2.0 and float(g.local[0]) == 0.0
+
+
+# ------------------------------------------------------------------------------------ dataset run: video sharding + record gather
+class _FakeEngine:
+    """Stands in for HipEngine on the CPU: deterministic outputs that depend on the frames only, so a sharded run must reproduce a
+    single-process run record for record.  (Host logic under test: window planning, bucketed streaming, merge, shard, gather.)"""
+    device = torch.device('cpu')
+
+    def forward(self, x, T, img_hw=None, **kw):
+        N = x.shape[0]
+        m = torch.stack([f.double().sum() for f in x]).float() / x[0].numel()   # per frame, independent of the batch it sits in
+        gaze = torch.stack([torch.stack([torch.sin(m + k), torch.cos(m * (c + 1)), -torch.ones_like(m)], dim=-1) for k in range(4) for c in [k]])
+        boxes = (m[:, None, None] * torch.arange(1, 13, dtype=torch.float32).view(1, 3, 4)).abs() + 1
+        scores = torch.sigmoid(m)[:, None].expand(N, 3) * torch.tensor([1.0, 0.9, 0.4])
+        return dict(gaze=gaze, boxes=boxes, scores=scores.contiguous())
+
+
+def _fake_videos():
+    lengths = [3, 7, 8, 30, 11, 19, 7, 45, 12]
+    vids = []
+    for i, L in enumerate(lengths):
+        g = torch.Generator().manual_seed(50 + i)
+        vids.append(dict(id=100 + i, file_names=[f'v{i}/{t:04d}.png' for t in range(L)], frames=torch.randn(L, 3, 32, 32, generator=g)))
+    return vids
+
+
+def _dataset_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from mcgaze_amd import harness
+    from mcgaze_amd.dist import gather_records, shard_videos
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    vids = _fake_videos()
+    idx = shard_videos(vids, world, rank)
+    recs = harness.run_videos(_FakeEngine(), [vids[i] for i in idx], batch_clips=5)
+    allrecs = gather_records(idx, recs, len(vids))
+    ret[rank] = (idx, allrecs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dataset_run_shards_videos_and_gathers_records_in_annotation_order():
+    """tools/test_gaze360_gaze.py under 2 ranks (gloo): whole videos per rank balanced by frame count, every rank streams its
+    windows through the engine in small batches, one object gather, records back in annotation order and identical to a
+    single-process run."""
+    from mcgaze_amd import harness
+    from mcgaze_amd.dist import shard_videos
+    world = 2
+    vids = _fake_videos()
+    single = harness.run_videos(_FakeEngine(), vids, batch_clips=64)
+    ret = mp.Manager().dict()
+    mp.spawn(_dataset_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    shards = [ret[r][0] for r in range(world)]
+    assert sorted(shards[0] + shards[1]) == list(range(len(vids))) and not set(shards[0]) & set(shards[1])
+    loads = [sum(len(vids[i]['file_names']) for i in sh) for sh in shards]
+    assert abs(loads[0] - loads[1]) <= max(len(v['file_names']) for v in vids) // 2 + 1, loads
+    for r in range(world):
+        got = ret[r][1]
+        assert [g['video_id'] for g in got] == [v['id'] for v in vids]
+        assert got == single
+    for w in (1, 3, 8):   # every video exactly once for other world sizes too
+        parts = [shard_videos(vids, w, r) for r in range(w)]
+        assert sorted(i for p in parts for i in p) == list(range(len(vids)))

@@ -329,6 +329,85 @@ def test_roi_align_all_levels(eng, dtype):
     assert float(got[-1].abs().max()) == 0.0  # a box entirely outside the map samples zeros
 
 
+def _affine_pyramid(H0, W0, channels=256):
+    """P2..P5 of a (4 H0) x (4 W0) frame, level l = base 10000 l + affine map (tests/roi_align_pins.py), NHWC f32 on the device."""
+    from tests import roi_align_pins as P
+    lv = []
+    for l in range(4):
+        m = P.affine_map(H0 >> l, W0 >> l, base=10000.0 * l, channels=1)[0, 0]           # [H, W]
+        lv.append(torch.from_numpy(m)[None, :, :, None].repeat(1, 1, 1, channels).contiguous().to('cuda:0'))
+    return lv
+
+
+def test_roi_align_hip_against_independent_pins(eng):
+    """The HIP RoIAlign kernel itself (f32) against the pins derived from the published mmcv kernel (tests/roi_align_pins.py):
+    every enumerated edge case on an affine map in closed form, the hand-worked non-affine numbers, and the level routing at
+    exactly 112 / 224 / 448 px (the level is visible in the sampled values: each pyramid level carries its own offset)."""
+    from tests import roi_align_pins as P
+    H0 = W0 = 16
+    pyr = _affine_pyramid(H0, W0, channels=8)
+    boxes = torch.tensor([b for _, b in P.EDGE_BOXES])[None]                      # one frame, 12 boxes, all < 112 px -> level 0
+    out, lv = eng.roi_align(pyr, boxes.to('cuda:0'))
+    torch.cuda.synchronize()
+    assert lv.cpu().tolist() == [0] * len(P.EDGE_BOXES)
+    got = out.cpu().reshape(len(P.EDGE_BOXES), 7, 7, 8)
+    for i, (name, box) in enumerate(P.EDGE_BOXES):
+        want = P.expected_affine(box, 4, H0, W0)[0]
+        np.testing.assert_allclose(got[i, :, :, 0].numpy(), want, rtol=0, atol=2e-4, err_msg=name)
+        assert torch.equal(got[i, :, :, 0], got[i, :, :, 7])
+    # level routing at the exact boundaries; a 2048 x 2048 frame so that every box lies inside its level's map
+    pyr = _affine_pyramid(512, 512, channels=8)
+    boxes = torch.tensor([b for b, _ in P.LEVEL_EDGE_BOXES])[None]
+    out, lv = eng.roi_align(pyr, boxes.to('cuda:0'))
+    torch.cuda.synchronize()
+    assert lv.cpu().tolist() == [l for _, l in P.LEVEL_EDGE_BOXES]
+    got = out.cpu().reshape(len(P.LEVEL_EDGE_BOXES), 7, 7, 8)
+    for i, (box, l) in enumerate(P.LEVEL_EDGE_BOXES):
+        want = P.expected_affine(box, 4 << l, 512 >> l, 512 >> l, base=10000.0 * l)[0]
+        np.testing.assert_allclose(got[i, :, :, 0].numpy(), want, rtol=0, atol=5e-3, err_msg=str(box))   # 3e4-sized values in f32
+    # hand-worked non-affine numbers
+    sq = torch.from_numpy(P.SQUARE_MAP[0, 0])[None, :, :, None].repeat(1, 1, 1, 8).contiguous().to('cuda:0')
+    pyr = [sq] + [torch.zeros(1, 4 >> i or 1, 4 >> i or 1, 8, device='cuda:0') for i in (1, 2, 3)]
+    out, _ = eng.roi_align(pyr, torch.tensor([[P.SQUARE_BOX]]).to('cuda:0'))
+    got = out.cpu().reshape(7, 7, 8)
+    for (ph, pw), v in P.SQUARE_HAND.items():
+        assert abs(float(got[ph, pw, 0]) - v) < 1e-5, ((ph, pw), float(got[ph, pw, 0]), v)
+
+
+def test_roi_align_hip_equals_scalar_statement(eng):
+    """The HIP kernel DIRECTLY against the scalar loop form of the published definition (oracle.roi_align_scalar, f32 arithmetic in
+    the kernel's order), on random features: random boxes that leave the map, the enumerated edge boxes scaled to every level,
+    zero-area and inverted boxes.  f32 on both sides -> agreement to a few ulp of the feature scale."""
+    from tests import roi_align_pins as P
+    rs = np.random.RandomState(11)
+    N, C = 2, 16
+    H0, W0 = 40, 56                                  # a 160 x 224 frame
+    feats = [rs.standard_normal((N, C, H0 >> i, W0 >> i)).astype(np.float32) for i in range(4)]
+    boxes = []
+    for scale in (1.0, 2.5, 5.0, 9.0):               # the edge boxes blown up so that they land on every level
+        for _, b in P.EDGE_BOXES:
+            boxes.append([v * scale for v in b])
+    xy = rs.uniform(-60, 230, size=(40, 2)); wh = rs.uniform(0, 500, size=(40, 2)) * rs.choice([1, 1, 1, -0.2], size=(40, 1))
+    boxes += np.concatenate([xy, xy + wh], axis=1).tolist()
+    while len(boxes) % N:
+        boxes.append([0., 0., 10., 10.])
+    bt = torch.tensor(boxes, dtype=torch.float32).reshape(N, -1, 4)
+    out, lv = eng.roi_align([torch.from_numpy(f).permute(0, 2, 3, 1).contiguous().to('cuda:0') for f in feats], bt.to('cuda:0'))
+    torch.cuda.synchronize()
+    ref_lv = orc.map_roi_levels(bt.reshape(-1, 4))
+    assert lv.cpu().tolist() == ref_lv.tolist() and set(ref_lv.tolist()) == {0, 1, 2, 3}
+    P_ = bt.shape[1]
+    got = out.cpu().reshape(-1, 7, 7, C).permute(0, 3, 1, 2).numpy()
+    worst = 0.0
+    for r in range(bt.shape[0] * P_):
+        l = int(ref_lv[r])
+        roi = np.array([[r // P_, *bt.reshape(-1, 4)[r].tolist()]], dtype=np.float32)
+        want = orc.roi_align_scalar(feats[l], roi, 1.0 / (4 << l))[0]
+        worst = max(worst, float(np.abs(got[r] - want).max()))
+    print(f'HIP RoIAlign vs scalar statement: max |d| = {worst:.2e} on unit-variance features')
+    assert worst < 4e-6
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,T', [(1, 7), (2, 3), (3, 1)])
 def test_decoder_stage(eng, sd, dtype, B, T):

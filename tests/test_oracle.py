@@ -109,3 +109,30 @@ def test_batched_semantics_equal_per_clip(golden_dir, weights):
     _, second = orc.forward(weights, img[T:], metas[T:], T)
     sep = torch.cat([first['gaze_score'], second['gaze_score']])
     assert (both['gaze_score'] - sep).abs().max() < 2e-5
+
+
+def test_roi_align_independent_pins():
+    """RoIAlign against pins derived from the PUBLISHED mmcv kernel, not from oracle code (tests/roi_align_pins.py): closed-form
+    values on an affine map for every enumerated edge case -- rows in (-1, 0), y == -1, y == H, the far-edge collapse, zero-area and
+    inverted boxes, samples outside on either side -- plus hand-worked numbers on a non-affine map.  Both the vectorised oracle
+    (used by the end-to-end goldens) and the scalar statement must reproduce them."""
+    from tests import roi_align_pins as P
+    H = W = 16
+    feat = P.affine_map(H, W, base=7.0, channels=2)
+    for name, box in P.EDGE_BOXES:
+        want = P.expected_affine(box, 4, H, W, base=7.0, channels=2)
+        rois = np.array([[0, *box]], dtype=np.float32)
+        got_v = orc.roi_align(torch.from_numpy(feat), torch.from_numpy(rois), 0.25).numpy()[0]
+        got_s = orc.roi_align_scalar(feat, rois, 0.25)[0]
+        np.testing.assert_allclose(got_v, want, rtol=0, atol=2e-4, err_msg=name)
+        np.testing.assert_allclose(got_s, want, rtol=0, atol=2e-4, err_msg=name)
+    # the cases exercise what they claim to
+    assert P.expected_affine(P.EDGE_BOXES[3][1], 4, H, W)[0, 0].max() == 0.0 and P.expected_affine(P.EDGE_BOXES[3][1], 4, H, W)[0, 6].min() > 0
+    assert P.expected_affine(P.EDGE_BOXES[6][1], 4, H, W)[0, 6].max() == 0.0
+    assert P.expected_affine(P.EDGE_BOXES[10][1], 4, H, W).max() == 0.0
+    rois = np.array([[0, *P.SQUARE_BOX]], dtype=np.float32)
+    for got in (orc.roi_align(torch.from_numpy(P.SQUARE_MAP), torch.from_numpy(rois), 0.25).numpy()[0, 0], orc.roi_align_scalar(P.SQUARE_MAP, rois, 0.25)[0, 0]):
+        for (ph, pw), v in P.SQUARE_HAND.items():
+            assert abs(float(got[ph, pw]) - v) < 1e-5, ((ph, pw), float(got[ph, pw]), v)
+    boxes = torch.tensor([b for b, _ in P.LEVEL_EDGE_BOXES])
+    assert orc.map_roi_levels(boxes).tolist() == [l for _, l in P.LEVEL_EDGE_BOXES]

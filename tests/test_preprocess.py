@@ -97,6 +97,40 @@ def test_resize_hand_cases():
     assert np.array_equal(po.resize_linear_u8(one, 3, 2), np.broadcast_to(one, (2, 3, 3)))      # single source pixel
 
 
+def test_resize_fixed_point_cases_worked_by_hand():
+    """cv2.resize(INTER_LINEAR) on 8-bit pixels, numbers worked out by hand from OpenCV's published fixed-point path (resize.cpp:
+    source coordinate (d + .5) * src/dst - .5, coefficients rint(f * 2048), horizontal pass in ints, vertical pass
+    (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2) -- up-scale, down-scale by a non-integer factor, odd sizes.
+    Every scale is a dyadic rational so that the coordinates are exact and the derivation does not depend on double rounding."""
+    # 1 x 2 -> 1 x 8 (scale 1/4): coordinates -.375 -.125 .125 .375 .625 .875 1.125 1.375 -> right-pixel coefficients 0 0 256 768 1280 1792
+    # then clamped (s >= src - 1 -> f = 0).  For [0, 255]: 255 * 256 = 65280 -> >> 4 = 4080 -> * 2048 >> 16 = 127 -> (127 + 2) >> 2 = 32;
+    # 195840 -> 12240 -> 382 -> 96;  326400 -> 20400 -> 637 -> 159;  456960 -> 28560 -> 892 -> 223
+    ramp = np.array([[[0] * 3, [255] * 3]], dtype=np.uint8)
+    assert po.resize_linear_u8(ramp, 8, 1)[0, :, 1].tolist() == [0, 0, 32, 96, 159, 223, 255, 255]
+    # 1 x 6 -> 1 x 4 (scale 3/2): coordinates .25 1.75 3.25 4.75 -> (s, f) = (0, .25) (1, .75) (3, .25) (4, .75); coefficients 1536 / 512
+    #   [1, 2, 4, 7, 11, 16]: 1*1536 + 2*512 = 2560 -> 160 -> 5 -> (5+2)>>2 = 1        (exact 1.25)
+    #                         2*512 + 4*1536 = 7168 -> 448 -> 14 -> 16>>2 = 4          (exact 3.5: rounds up)
+    #                         7*1536 + 11*512 = 16384 -> 1024 -> 32 -> 34>>2 = 8       (exact 8.0)
+    #                         11*512 + 16*1536 = 30208 -> 1888 -> 59 -> 61>>2 = 15     (exact 14.75)
+    row = np.array([[[v] * 3 for v in (1, 2, 4, 7, 11, 16)]], dtype=np.uint8)
+    assert po.resize_linear_u8(row, 4, 1)[0, :, 2].tolist() == [1, 4, 8, 15]
+    assert po.resize_linear_u8(row.transpose(1, 0, 2), 1, 4)[:, 0, 0].tolist() == [1, 4, 8, 15]          # the same along y
+    row = np.array([[[v] * 3 for v in (0, 40, 80, 120, 160, 200)]], dtype=np.uint8)
+    assert po.resize_linear_u8(row, 4, 1)[0, :, 0].tolist() == [10, 70, 130, 190]
+    # 3 x 3 -> 6 x 6 (odd source, scale 1/2), v[y][x] = 10 y + 3 x: output (1, 1) has (s, f) = (0, .25) on both axes:
+    #   row 0: 0*1536 + 3*512 = 1536;  row 1: 10*1536 + 13*512 = 22016;  vertical: (1536 * (1536 >> 4)) >> 16 = 2,
+    #   (512 * (22016 >> 4)) >> 16 = 10  ->  (2 + 10 + 2) >> 2 = 3            (exact 3.25)
+    # output (4, 2): y (s, f) = (1, .75), x (s, f) = (0, .75): row 1: 10*512 + 13*1536 = 25088, row 2: 20*512 + 23*1536 = 45568;
+    #   (512 * (25088 >> 4)) >> 16 = 12 (12.25), (1536 * (45568 >> 4)) >> 16 = 66 (66.75) -> (12 + 66 + 2) >> 2 = 20   (exact 19.75)
+    # corners replicate: output (0, 0) = v[0][0] = 0, output (5, 5) = v[2][2] = 26
+    v = np.array([[[10 * y + 3 * x] * 3 for x in range(3)] for y in range(3)], dtype=np.uint8)
+    out = po.resize_linear_u8(v, 6, 6)
+    assert (int(out[1, 1, 0]), int(out[4, 2, 0]), int(out[0, 0, 0]), int(out[5, 5, 0])) == (3, 20, 0, 26)
+    # 5 x 7 -> 10 x 14 and back keeps a constant image constant (no drift from the +2 >> 2 rounding)
+    c = np.full((5, 7, 3), 77, np.uint8)
+    assert np.array_equal(po.resize_linear_u8(po.resize_linear_u8(c, 14, 10), 7, 5), c)
+
+
 def test_normalize_pad_format_hand_cases():
     img = np.zeros((2, 3, 3), np.uint8)
     img[0, 0] = (10, 20, 30)   # B, G, R

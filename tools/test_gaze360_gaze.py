@@ -22,6 +22,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcgaze_amd import harness, init_detector, metric  # noqa: E402
+from mcgaze_amd.dist import gather_records, shard_videos  # noqa: E402
 from mcgaze_amd.pipeline import DevicePipeline  # noqa: E402
 
 
@@ -58,18 +59,6 @@ def parse_args(argv=None):
     return a
 
 
-def shard_videos(videos, world, rank):
-    """Whole videos per rank (the overlap merge needs all windows of a video together), balanced by frame count."""
-    order = sorted(range(len(videos)), key=lambda i: -len(videos[i]['file_names']))
-    load, mine = [0] * world, []
-    for i in order:
-        r = min(range(world), key=lambda k: load[k])
-        load[r] += len(videos[i]['file_names'])
-        if r == rank:
-            mine.append(i)
-    return sorted(mine)
-
-
 def main(argv=None):
     a = parse_args(argv)
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
@@ -88,11 +77,7 @@ def main(argv=None):
     rng = np.random.RandomState(a.seed + rank) if a.seed is not None else None
     recs = harness.run_annotation(model.engine(), dict(videos=[anno['videos'][i] for i in idx]), a.root, pipe, batch_clips=a.batch_clips, rng=rng)
     if world > 1:
-        import torch.distributed as dist
-        parts = [None] * world
-        dist.all_gather_object(parts, list(zip(idx, recs)))
-        merged = dict(p for part in parts for p in part)
-        recs = [merged[i] for i in range(len(anno['videos']))]
+        recs = gather_records(idx, recs, len(anno['videos']))
     if rank == 0:
         path = harness.dump_results(recs, a.config, a.json)
         print('Done', path)
