@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 3
+#define MCG_ABI_VERSION 4
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
 /* MCG_BF16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
@@ -125,11 +125,12 @@ enum {
   MCG_SW_HEAD_CLS_B, /* f32 [3]                                                  */
   MCG_SW_HEAD_REG_W, /* f32 [3 clues][4][256]   (face, eyes, head)_fc_reg.weight */
   MCG_SW_HEAD_REG_B, /* f32 [3][4]                                               */
-  /* MFMA-fragment-major copies of three 256x256 matrices for the fused row-block chain (bf16 engine; the f32 engine ignores them
+  /* MFMA-fragment-major copies of [32 t][256] matrices for the fused row-block chain / attention block (bf16 engine; the f32 engine ignores them
    * and may be given the row-major pointers again): WF[t][ks][lane][e] = W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e],
    * t < 8, ks < 16, lane < 64, e < 8 -- one wave-wide 16-byte load per (column tile, K-step) is then 1 KiB contiguous. */
   MCG_SW_OUT_PROJ_WF, MCG_SW_CLS_FC_WF,
   MCG_SW_REG_FC_WF,  /* [3] x fragment-major */
+  MCG_SW_IN_PROJ_WF, /* in_proj_weight [768][256] fragment-major (t < 24 column tiles) for the fused attention block (attn_block.hpp) */
   MCG_SW_COUNT
 };
 enum {

@@ -3,39 +3,30 @@
 // gaze head tail, and query initialisation.  GEMM-shaped work goes through igemm.hpp.
 #include "igemm.hpp"
 #include "chain.hpp"
+#include "attn_block.hpp"
 
 #include <string.h>
 
 // ------------------------------------------------------------------------------------------------
 // Attention core (nn.MultiheadAttention inside mmcv's wrapper, gaze_stqi_head.py:151,162):
 // 8 heads x 32 dims, softmax over the L tokens of one group.  One workgroup per group; thread =
-// (head, dim); q.k reductions are 32-lane shuffles; softmax is the online (running max) form.
+// (query token, head), no cross-lane reduction (attn_block.hpp: attend_row_head).
+// The bf16 engine runs both attention passes of a stage in attn_block_kernel instead whenever a clip's 3 T rows fit one MFMA tile.
 //   spatial : group = frame,        tokens r = g*3 + i            (L = 3 clues)
 //   temporal: group = (clip, clue), tokens r = (b*T + i)*3 + c    (L = T frames)
 template <typename T>
 __global__ __launch_bounds__(256) void attn_core_kernel(const T* __restrict__ qkv, T* __restrict__ out, int L, int temporal, int clip_len, float scale) {
-  const int g = blockIdx.x, tid = threadIdx.x;
+  const int g = blockIdx.x;
   long long base; int step;
   if (temporal) { const int b = g / 3, c = g - b * 3; base = (long long)b * clip_len * 3 + c; step = 3; }
   else { base = (long long)g * 3; step = 1; }
   const int D = 256;
-  for (int i = 0; i < L; ++i) {
+  for (int pair = threadIdx.x; pair < L * 8; pair += 256) {   // thread = (query token of the group, head)
+    const int i = pair >> 3, h = pair & 7;
     const long long ri = base + (long long)i * step;
-    const float q = Elem<T>::ld(qkv + ri * (3 * D) + tid) * scale;
-    float m = -INFINITY, l = 0.f, acc = 0.f;
-    for (int j = 0; j < L; ++j) {
-      const long long rj = base + (long long)j * step;
-      float s = q * Elem<T>::ld(qkv + rj * (3 * D) + D + tid);
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);  // within the 32 lanes of one head
-      const float v = Elem<T>::ld(qkv + rj * (3 * D) + 2 * D + tid);
-      const float mn = fmaxf(m, s);
-      const float corr = expf(m - mn), pj = expf(s - mn);
-      acc = acc * corr + pj * v;
-      l = l * corr + pj;
-      m = mn;
-    }
-    Elem<T>::st(out + ri * D + tid, acc / l);
+    attend_row_head<T>(qkv + ri * (3 * D) + h * 32,
+                       [&](int j) { return qkv + (base + (long long)j * step) * (3 * D) + D + h * 32; },
+                       [&](int j) { return qkv + (base + (long long)j * step) * (3 * D) + 2 * D + h * 32; }, L, scale, out + ri * D + h * 32);
   }
 }
 
@@ -292,10 +283,13 @@ __global__ __launch_bounds__(256) void heads_kernel(const T* __restrict__ cls_fe
 template <typename T>
 __global__ __launch_bounds__(256) void gaze_tail_kernel(const T* __restrict__ feats, const float* __restrict__ w_out, const float* __restrict__ b_out,
                                                         const float* __restrict__ w_fuse, const float* __restrict__ b_fuse,
-                                                        float* __restrict__ gaze_out, int N) {
+                                                        float* __restrict__ gaze_out, int N,
+                                                        const float* __restrict__ cls_logits, float* __restrict__ scores_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + wave;
   if (n >= N) return;
+  // scores = sigmoid(last stage's logits) (multiclue_gaze_roi_head.py:351-352): the path's other tail, three values per frame
+  if (scores_out && lane < 3) scores_out[n * 3 + lane] = 1.0f / (1.0f + expf(-cls_logits[n * 3 + lane]));
   float o[6][3];
 #pragma unroll
   for (int br = 0; br < 6; ++br) {
@@ -351,12 +345,6 @@ __global__ void init_queries_kernel(const float* __restrict__ init_boxes, const 
       boxes[((long long)n * 3 + q) * 4 + d] = v;
     }
   }
-}
-
-// scores = sigmoid(logits) (multiclue_gaze_roi_head.py:351-352)
-__global__ void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) y[i] = 1.0f / (1.0f + expf(-x[i]));
 }
 
 // ================================================================================================
@@ -419,7 +407,16 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
   const void* xin = obj_in;
   char* xout[2] = {w.x1, w.x2};
   const bool chain_attn = bf && ctx.chain;
-  for (int pass = 0; pass < 2; ++pass) {
+  const bool block_attn = chain_attn && attn_block_applicable(clip_length);
+  if (block_attn) {  // both passes, one launch, one clip per workgroup (attn_block.hpp); bit-identical to the loop below
+    AttnBlockParams ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.x = obj_in; ap.y = w.x2; ap.w_in = W[MCG_SW_IN_PROJ_WF]; ap.b_in = f32w[MCG_SW_IN_PROJ_B];
+    ap.w_out = W[MCG_SW_OUT_PROJ_WF]; ap.b_out = f32w[MCG_SW_OUT_PROJ_B]; ap.g = f32w[MCG_SW_ATTN_LN_G]; ap.b = f32w[MCG_SW_ATTN_LN_B];
+    ap.num_clips = B; ap.T = clip_length; ap.scale = 1.0f / sqrtf(32.f);
+    if (launch_attn_block(s, ap)) { mcg_set_error("attn_block launch failed"); return MCG_ERR_HIP; }
+  }
+  for (int pass = 0; pass < 2 && !block_attn; ++pass) {
     MCG_TRY(launch_linear(s, dt, xin, 256, W[MCG_SW_IN_PROJ_W], f32w[MCG_SW_IN_PROJ_B], nullptr, 0, w.qkv, 768, R, 256, 768, 0, ctx));
     if (bf) launch_attn<bf16_t>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
     else launch_attn<float>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
@@ -507,10 +504,10 @@ extern "C" size_t mcg_gaze_head_workspace_bytes(mcg_dtype dt, int num_frames) {
 
 extern "C" int mcg_gaze_head(mcg_stream s, mcg_dtype dt, const void* const W[MCG_GW_COUNT], const void* obj, int N,
                              float* gaze_out, void* ws, size_t ws_bytes) {
-  return gaze_head_ctx((hipStream_t)s, dt, W, obj, N, gaze_out, ws, ws_bytes, McgCtx());
+  return gaze_head_ctx((hipStream_t)s, dt, W, obj, N, gaze_out, ws, ws_bytes, McgCtx(), nullptr, nullptr);
 }
 int gaze_head_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_GW_COUNT], const void* obj, int N, float* gaze_out,
-                  void* ws, size_t ws_bytes, const McgCtx& ctx) {
+                  void* ws, size_t ws_bytes, const McgCtx& ctx, const float* cls_logits, float* scores_out) {
   MCG_CHECK_ARG(W && obj && gaze_out && ws && N > 0, "mcg_gaze_head: bad argument");
   for (int i = 0; i < MCG_GW_COUNT; ++i) MCG_CHECK_ARG(W[i], "mcg_gaze_head: weight table entry %d is null", i);
   if (ws_bytes < mcg_gaze_head_workspace_bytes(dt, N)) { mcg_set_error("mcg_gaze_head: workspace too small"); return MCG_ERR_WORKSPACE; }
@@ -521,23 +518,24 @@ int gaze_head_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_GW_COUNT]
   const float* lg = (const float*)W[MCG_GW_LN_G];
   const float* lb = (const float*)W[MCG_GW_LN_B];
   for (int layer = 0; layer < 2; ++layer) {
-    for (int k = 0; k < 2; ++k) {  // k = 0 gaze MLPs, 1 confidence MLPs; 3 clue groups per launch
+    {  // six branches (3 gaze MLPs, 3 confidence MLPs; branch = 3 k + clue) as ONE grouped launch: layer 0 reads token `clue` of
+       // every frame for both k (x_g_period = 3), layer 1 its own branch's hidden rows
       IgemmParams p;
       memset(&p, 0, sizeof(p));
       p.M = N; p.Ho = 1; p.Wo = 1; p.H = 1; p.W = 1; p.Cin = 256; p.KH = 1; p.KW = 1; p.stride = 1; p.Cout = 256; p.nocheck = 1;
       p.splitk = 1; p.tiles_per_slice = 1 << 30;
-      if (layer == 0) { p.x = obj; p.xs_n = 768; p.x_g = 256; }                       // token c of every frame
-      else { p.x = h1 + (size_t)k * 3 * N * 256 * es; p.xs_n = 256; p.x_g = (long long)N * 256; }
-      p.w = fcw + ((size_t)(k * 3) * 2 + layer) * 65536 * es; p.w_g = 2 * 65536;
-      p.y = raw + (size_t)k * 3 * N * 256 * es; p.y_g = (long long)N * 256; p.y_row_stride = 256;
-      MCG_TRY(launch_igemm(s, dt, p, 3, ctx));
+      if (layer == 0) { p.x = obj; p.xs_n = 768; p.x_g = 256; p.x_g_period = 3; }
+      else { p.x = h1; p.xs_n = 256; p.x_g = (long long)N * 256; }
+      p.w = fcw + (size_t)layer * 65536 * es; p.w_g = 2 * 65536;
+      p.y = raw; p.y_g = (long long)N * 256; p.y_row_stride = 256;
+      MCG_TRY(launch_igemm(s, dt, p, 6, ctx));
     }
     LnParams q = ln_simple(raw, lg + layer * 256, lb + layer * 256, 1, layer == 0 ? h1 : h2, 6 * N, 256);
     q.rows_per_group = N; q.param_stride = 2 * 256;  // LN params are [6][2][256]
     MCG_TRY(launch_ln(s, dt, q));
   }
-  if (dt == MCG_BF16) hipLaunchKernelGGL(gaze_tail_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, (const bf16_t*)h2, (const float*)W[MCG_GW_OUT_W], (const float*)W[MCG_GW_OUT_B], (const float*)W[MCG_GW_FUSE_W], (const float*)W[MCG_GW_FUSE_B], gaze_out, N);
-  else hipLaunchKernelGGL(gaze_tail_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, (const float*)h2, (const float*)W[MCG_GW_OUT_W], (const float*)W[MCG_GW_OUT_B], (const float*)W[MCG_GW_FUSE_W], (const float*)W[MCG_GW_FUSE_B], gaze_out, N);
+  if (dt == MCG_BF16) hipLaunchKernelGGL(gaze_tail_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, (const bf16_t*)h2, (const float*)W[MCG_GW_OUT_W], (const float*)W[MCG_GW_OUT_B], (const float*)W[MCG_GW_FUSE_W], (const float*)W[MCG_GW_FUSE_B], gaze_out, N, cls_logits, scores_out);
+  else hipLaunchKernelGGL(gaze_tail_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, (const float*)h2, (const float*)W[MCG_GW_OUT_W], (const float*)W[MCG_GW_OUT_B], (const float*)W[MCG_GW_FUSE_W], (const float*)W[MCG_GW_FUSE_B], gaze_out, N, cls_logits, scores_out);
   MCG_CHECK_LAUNCH("gaze_tail");
   return MCG_OK;
 }
@@ -550,10 +548,5 @@ int launch_init_queries(hipStream_t s, mcg_dtype dt, const float* init_boxes, co
   if (dt == MCG_BF16) hipLaunchKernelGGL(init_queries_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, init_boxes, (const bf16_t*)init_feats, img_hw, H, W, boxes, (bf16_t*)obj, N);
   else hipLaunchKernelGGL(init_queries_kernel<float>, dim3(grid), dim3(256), 0, s, init_boxes, (const float*)init_feats, img_hw, H, W, boxes, (float*)obj, N);
   MCG_CHECK_LAUNCH("init_queries");
-  return MCG_OK;
-}
-int launch_sigmoid(hipStream_t s, const float* x, float* y, int n) {
-  hipLaunchKernelGGL(sigmoid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, n);
-  MCG_CHECK_LAUNCH("sigmoid");
   return MCG_OK;
 }

@@ -22,7 +22,6 @@ int launch_roi_align(hipStream_t s, mcg_dtype dt, const void* const feats[4], co
                      int32_t* levels_out);
 int launch_init_queries(hipStream_t s, mcg_dtype dt, const float* init_boxes, const void* init_feats, const int* img_hw, int H, int W,
                         float* boxes, void* obj, int N);
-int launch_sigmoid(hipStream_t s, const float* x, float* y, int n);
 
 struct mcg_engine {
   mcg_dtype dt;
@@ -476,8 +475,7 @@ extern "C" int mcg_decoder_forward(mcg_engine* e, mcg_stream s_, const void* con
     char* t = obj_in; obj_in = obj_out; obj_out = t;
     if (st != e->num_stages - 1) { float* tb = b_in; b_in = b_out; b_out = tb; }
   }
-  MCG_TRY(launch_sigmoid(s, c.cls, scores_out, N * 3));
-  MCG_TRY(gaze_head_ctx(s, e->dt, e->gaze_w, obj_in, N, gaze_out, c.gaze_ws, c.gaze_bytes, e->ctx));
+  MCG_TRY(gaze_head_ctx(s, e->dt, e->gaze_w, obj_in, N, gaze_out, c.gaze_ws, c.gaze_bytes, e->ctx, c.cls, scores_out));
   return MCG_OK;
 }
 

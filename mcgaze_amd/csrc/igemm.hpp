@@ -29,6 +29,7 @@ struct IgemmParams {
   int relu, res_mode, Hr, Wr;
   float rscale_h, rscale_w;
   long long x_g, w_g, y_g, res_g;  // per-group element offsets (blockIdx.z)
+  int x_g_period;                  // > 0: the A operand of group g is that of group g % x_g_period (several weight sets over the same inputs)
   int bias_g;
   int splitk, tiles_per_slice;
   // optional second A source, K-concatenated after the first (1x1 taps only): D = [A1 | A2] . [W1 | W2]^T.
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
   const int g = blockIdx.z, slice = blockIdx.y;
 
-  const T* __restrict__ X = (const T*)p.x + (long long)g * p.x_g;
+  const T* __restrict__ X = (const T*)p.x + (long long)(p.x_g_period > 0 ? g % p.x_g_period : g) * p.x_g;
   const T* __restrict__ Wt = (const T*)p.w + (long long)g * p.w_g;
   const T* __restrict__ X2 = (const T*)p.x2;
   const long long K = (long long)p.KH * p.KW * p.Cin + (X2 ? p.Cin2 : 0);
@@ -297,5 +298,6 @@ int stem_forward_ctx(hipStream_t s, mcg_dtype dt, const float* img, const void* 
 int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_COUNT], const void* roi_feat, const void* obj_in,
                       const float* boxes_in, int N, int clip_length, void* obj_out, float* boxes_out, float* cls_out,
                       const float stds[4], void* ws, size_t ws_bytes, const McgCtx& ctx);
+// cls_logits / scores_out (optional, [N][3]): the last stage's logits -> sigmoid scores, written by the gaze tail kernel
 int gaze_head_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_GW_COUNT], const void* obj, int N, float* gaze_out,
-                  void* ws, size_t ws_bytes, const McgCtx& ctx);
+                  void* ws, size_t ws_bytes, const McgCtx& ctx, const float* cls_logits, float* scores_out);

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   const int kt_end = min(KT, kt_begin + p.tiles_per_slice);
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int HoWo = p.Ho * p.Wo;
-  const u32x4 srd_a = make_srd((const T*)p.x + (long long)g * p.x_g);
+  const u32x4 srd_a = make_srd((const T*)p.x + (long long)(p.x_g_period > 0 ? g % p.x_g_period : g) * p.x_g);
   const u32x4 srd_b = make_srd((const T*)p.w + (long long)g * p.w_g);
   const u32x4 srd_a2 = make_srd(p.x2 ? p.x2 : p.x);
 

@@ -274,6 +274,49 @@ class HipEngine:
         return hw
 
 
+class GraphedForward:
+    """Latency path (BASELINE.json configs[0], the reference harness's usage: ONE clip per forward, tools/test_gaze360_gaze.py:107-111).
+    A single 7-frame clip is ~170 short launches whose GPU time is far below their launch cost, so the whole forward --
+    trunk, 4 x (RoIAlign + decoder stage), gaze head -- is captured ONCE into a HIP graph for a fixed (N, H, W, clip_length) and
+    replayed: one graph launch per clip.  Inputs are copied into the graph's static buffer on the caller's stream; the
+    returned tensors are the graph's static outputs (valid until the next call).  Results are bit-identical to engine.forward
+    (tests/test_gpu_forward.py::test_graphed_forward_is_bit_identical)."""
+
+    def __init__(self, engine, num_frames, H, W, clip_length, with_img_hw=False):
+        e = self.e = engine
+        self.N, self.T = num_frames, clip_length
+        dev = e.device
+        with torch.cuda.device(dev):
+            self.img = torch.zeros(num_frames, 3, H, W, dtype=torch.float32, device=dev)
+            self.hw = torch.zeros(num_frames, 2, dtype=torch.int32, device=dev) if with_img_hw else None
+            if self.hw is not None:
+                self.hw[:, 0], self.hw[:, 1] = H, W
+            self.out = dict(gaze=torch.zeros(4, num_frames, 3, device=dev), boxes=torch.zeros(num_frames, 3, 4, device=dev),
+                            scores=torch.zeros(num_frames, 3, device=dev))
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):          # eager warm-up on the capture stream: workspace allocation, side-stream probe
+                for _ in range(2):
+                    e.forward(self.img, clip_length, img_hw=self.hw, out=self.out)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                e.forward(self.img, clip_length, img_hw=self.hw, out=self.out)
+
+    def __call__(self, img, img_hw=None):
+        self.e._check_img(img)
+        if tuple(img.shape) != tuple(self.img.shape):
+            raise L.McgError(f'GraphedForward was captured for {tuple(self.img.shape)}, got {tuple(img.shape)}')
+        self.img.copy_(img, non_blocking=True)
+        if img_hw is not None:
+            if self.hw is None:
+                raise L.McgError('GraphedForward was captured without img_hw (with_img_hw=True to enable)')
+            self.hw.copy_(self.e.img_hw_tensor(img_hw, self.N), non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
 _PIPELINE_STREAMS = {}
 
 

@@ -49,14 +49,15 @@ def ohwi(w):
 
 
 def frag_major(w):
-    """[..., 256 out, 256 in] -> MFMA-fragment-major [..., t=8][ks=16][lane=64][e=8] with
+    """[..., 32 nt out, 256 in] -> MFMA-fragment-major [..., t=nt][ks=16][lane=64][e=8] with
     WF[t][ks][lane][e] = W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e] (include/mcgaze_hip.h, MCG_SW_*_WF)."""
     lead = w.shape[:-2]
-    assert w.shape[-2:] == (256, 256)
-    v = w.reshape(*lead, 8, 32, 16, 2, 8)                      # t, n, ks, half, e
+    rows = w.shape[-2]
+    assert w.shape[-1] == 256 and rows % 32 == 0
+    v = w.reshape(*lead, rows // 32, 32, 16, 2, 8)             # t, n, ks, half, e
     n = len(lead)
     v = v.permute(*range(n), n, n + 2, n + 3, n + 1, n + 4)    # t, ks, half, n, e  -> lane = 32 half + n
-    return v.contiguous().reshape(*lead, 256, 256)
+    return v.contiguous().reshape(*lead, rows, 256)
 
 
 def split_pack(w):
@@ -153,7 +154,7 @@ class PackedWeights:
                 HEAD_CLS_B=vec(torch.cat([sd[p + f'.{c}_fc_cls.bias'] for c in CLUES])),
                 HEAD_REG_W=vec(torch.stack([sd[p + f'.{c}_fc_reg.weight'] for c in CLUES])),
                 HEAD_REG_B=vec(torch.stack([sd[p + f'.{c}_fc_reg.bias'] for c in CLUES])))
-            for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W'):   # fragment-major copies for the fused chain kernel (chain.hpp, bf16 engine only)
+            for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W', 'IN_PROJ_W'):   # fragment-major copies for the fused chain / attention-block kernels (bf16 engine only)
                 st[k + 'F'] = frag_major(st[k]) if dtype == torch.bfloat16 else st[k]
             assert st['HEAD_CLS_W'].shape == (3, 256), 'use_sigmoid=True heads expected (gaze_stqi_head.py:72-75)'
             self.stages.append(st)

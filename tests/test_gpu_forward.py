@@ -346,3 +346,29 @@ def test_bench_schedule_is_bitwise_equal_to_per_clip_calls(precision):
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
+def test_graphed_forward_is_bit_identical(engines, precision):
+    """The HIP-graph latency path (engine.GraphedForward: one graph launch per clip) against the eager call, on several clips and
+    with per-frame img_shape; also a 16-clip batch (two concurrent frame ranges inside the graph: fork / join events are captured)."""
+    from mcgaze_amd.engine import GraphedForward
+    e = engines[precision]
+    T = 7
+    g = GraphedForward(e, T, 224, 224, T, with_img_hw=True)
+    for seed in (1, 2, 3):
+        img = torch.from_numpy(synth.make_clips(900 + seed, 1, T)).to('cuda:0')
+        hw = np.tile(np.array([200 + seed, 210], dtype=np.int32), (T, 1))
+        want = {k: v.clone() for k, v in e.forward(img, T, img_hw=hw).items()}
+        got = g(img, img_hw=hw)
+        torch.cuda.synchronize()
+        for k in want:
+            assert torch.equal(got[k], want[k]), (seed, k)
+    B = 16
+    gb = GraphedForward(e, B * T, 224, 224, T)
+    img = torch.from_numpy(synth.make_clips(77, B, T)).to('cuda:0')
+    want = {k: v.clone() for k, v in e.forward(img, T).items()}
+    got = gb(img)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(got[k], want[k]), k

@@ -434,9 +434,10 @@ def test_decoder_stage(eng, sd, dtype, B, T):
         assert scale_err(boxes_o, boxes_r) < tol, 'boxes'
 
 
-@pytest.mark.parametrize('B,T', [(1, 7), (5, 3), (11, 1)])
+@pytest.mark.parametrize('B,T', [(1, 7), (5, 3), (11, 1), (2, 10), (1, 11), (64, 7)])
 def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T):
-    """chain.hpp (towers and attention out-projection + LayerNorm as single launches) keeps the K order, the bf16 rounding points
+    """attn_block.hpp (both attention passes of a stage as one launch, one clip per workgroup, for 3 T <= 32; T = 11 takes the
+    per-pass chain) and chain.hpp (towers and attention out-projection + LayerNorm as single launches) keep the K order, the bf16 rounding points
     and the LayerNorm reduction order of the launch sequence it replaces -- incl. row counts that are not a multiple of its 32-row
     block."""
     from mcgaze_amd.packing import PackedWeights
