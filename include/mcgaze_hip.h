@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 4
+#define MCG_ABI_VERSION 5
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
 /* MCG_BF16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
@@ -169,6 +169,9 @@ typedef struct {
   const void* w;      /* OHWI dtype, BN folded */
   const float* bias;  /* f32 [Cout] */
   int cin, cout, k, stride, pad;
+  const void* wf;     /* optional (MCG_BF16, 1x1 convs): MFMA-fragment-major copy of w, [cout/32][cin/16][64 lanes][8]:
+                         wf[t][ks][lane][e] = w[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e].  With it the engine runs a bottleneck's
+                         conv3 (+ residual) and the next block's conv1 as one kernel (pw_pair.hpp); NULL -> layer-granular launches */
 } mcg_conv_weights;
 
 typedef struct {
@@ -196,7 +199,8 @@ void mcg_engine_destroy(mcg_engine* e);
  *   max_range_frames  >= 0  lowers the frames-per-range cap (0 = what fits the 2 GiB descriptor window)
  *   tile              forces a contraction tile id (0 = heuristic), see mcg_conv_desc.tile
  *   staged_gemm, conv3x3_c64, stem_fused, decoder_chain   0/1 kernel-variant switches (defaults 0, 1, 1, 1)
- *   fused_bottleneck  0/1 experimental one-kernel layer1 identity block (default 0) */
+ *   fused_bottleneck  0/1 experimental one-kernel layer1 identity block (default 0)
+ *   pointwise_pair    0/1 conv3 (+ residual) of a block and conv1 of the next as one kernel in layer1 / layer2 (bf16; default 1) */
 int mcg_engine_set_option(mcg_engine* e, const char* name, int value);
 /* chunk_frames: the trunk runs in chunks of this many frames so that layer outputs stay
  * resident in the 256 MiB Infinity Cache (0 = all frames in one pass). */

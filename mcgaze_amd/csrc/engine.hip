@@ -9,6 +9,7 @@
 // kernels: 448 frames 9.36 -> 8.75 ms (tools/trunk_two_streams.py).
 #include "igemm.hpp"
 #include "bottleneck_fused.hpp"
+#include "pw_pair.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -45,6 +46,7 @@ struct mcg_engine {
   int trunk_streams = 2;       // concurrent frame ranges of the trunk
   int max_range_frames = 0;    // 0 = what fits the 2 GiB descriptor window
   bool fused_block = false;    // experimental one-kernel layer1 identity bottleneck (bottleneck_fused.hpp)
+  bool pw_pair = true;         // layer1 / layer2 (bf16): conv3 (+ residual) and the next block's conv1 as one kernel (pw_pair.hpp)
   std::mutex mu;               // one forward at a time per engine: the fork/join events and side streams are shared state
 };
 // Side-stream candidates are created ONCE per device and shared by every engine of the process.  Measured (tools/leg_order_probe.py):
@@ -184,6 +186,7 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "stem_fused")) e->ctx.stem_fused = value != 0;
   else if (!strcmp(name, "decoder_chain")) e->ctx.chain = value != 0;
   else if (!strcmp(name, "fused_bottleneck")) e->fused_block = value != 0;
+  else if (!strcmp(name, "pointwise_pair")) e->pw_pair = value != 0;
   else { mcg_set_error("mcg_engine_set_option: unknown option '%s'", name); return MCG_ERR_ARG; }
   return MCG_OK;
 }
@@ -288,6 +291,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
   MCG_TRY(stem_forward_ctx(s, dt, img + (size_t)f0 * 3 * H * W, e->stem.w, e->stem.bias, t.x0, n, H, W, t.stem_ws, t.stem_bytes, e->ctx));
   const void* x = t.x0;
   int h = H / 4, w = W / 4, ci = 0;
+  bool o1_ready = false;   // t.o1 already holds this block's conv1 output (written by the previous block's pointwise-pair kernel)
   for (int l = 0; l < 4; ++l) {
     for (int b = 0; b < e->blocks[l]; ++b) {
       const mcg_conv_weights& c1 = e->convs[ci], &c2 = e->convs[ci + 1], &c3 = e->convs[ci + 2];
@@ -305,8 +309,31 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
         ci += 3;
         continue;
       }
-      MCG_TRY(conv_call(e, s, dt, c1, x, n, h, w, t.o1, 1, nullptr, MCG_RES_NONE, 0, 0));
+      if (!o1_ready) MCG_TRY(conv_call(e, s, dt, c1, x, n, h, w, t.o1, 1, nullptr, MCG_RES_NONE, 0, 0));
+      o1_ready = false;
       MCG_TRY(conv_call(e, s, dt, c2, t.o1, n, h, w, t.o2, 1, nullptr, MCG_RES_NONE, 0, 0));
+      // conv3 (+ downsample / + residual) together with the NEXT block's conv1 (pw_pair.hpp): layer1 / layer2, where both are
+      // HBM-bound.  The next conv1 is the following block's, or the next layer's first (1x1, stride 1 on this block's output).
+      const int ci_next = ci + (has_ds ? 4 : 3);
+      const mcg_conv_weights* c3w = has_ds ? (e->c3_ds[l].w ? &e->c3_ds[l] : nullptr) : &c3;
+      const mcg_conv_weights* c1n = ci_next < (int)e->convs.size() ? &e->convs[ci_next] : nullptr;
+      const int k2 = has_ds ? e->convs[ci + 3].cin : 0;
+      if (dt == MCG_BF16 && e->pw_pair && l == 0 && c3w && c1n && c3w->wf && c1n->wf && c3w->bias && c1n->bias && c1n->k == 1 && c1n->stride == 1 &&
+          c1n->cin == c3.cout && pw_pair_applicable(c3.cin, k2, has_ds ? e->convs[ci + 3].stride : 1, c3.cout, c1n->cout, (long long)n * ho * wo) && (long long)n * ho * wo < 0x7fffffffll) {
+        PwPairParams pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.a1 = t.o2; pp.K1 = c3.cin;
+        if (has_ds) { pp.a2 = x; pp.K2 = k2; pp.stride2 = e->convs[ci + 3].stride; pp.H2 = h; pp.W2 = w; }
+        else pp.res = x;
+        pp.w3f = c3w->wf; pp.b3 = c3w->bias; pp.y = y;
+        pp.w1f = c1n->wf; pp.b1 = c1n->bias; pp.z = t.o1;
+        pp.M = n * ho * wo; pp.C = c3.cout; pp.C2 = c1n->cout; pp.Ho = ho; pp.Wo = wo;
+        if (launch_pw_pair(s, pp)) { mcg_set_error("pw_pair launch failed"); return MCG_ERR_HIP; }
+        o1_ready = true;
+        x = y; h = ho; w = wo;
+        ci = ci_next;
+        continue;
+      }
       if (has_ds && e->c3_ds[l].w) {
         // conv3 and the downsample conv as ONE K-concatenated GEMM: relu([o2 | x@stride] . [W3 | Wd]^T + b3 + bd);
         // the downsample output never goes to HBM and conv3 reads no residual.

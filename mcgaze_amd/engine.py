@@ -165,7 +165,8 @@ class HipEngine:
         self.weights = PackedWeights(state_dict, depth=depth, num_stages=num_stages, dtype=self.dtype, device=self.device,
                                      fuse_downsample=fuse_downsample, split=self.code == L.MCG_BF16X3)
         w = self.weights
-        mk = lambda c: L.ConvWeights(c['w'].data_ptr(), c['bias'].data_ptr(), c['cin'], c['cout'], c['k'], c['stride'], c['pad'])
+        mk = lambda c: L.ConvWeights(c['w'].data_ptr(), c['bias'].data_ptr(), c['cin'], c['cout'], c['k'], c['stride'], c['pad'],
+                                     c['wf'].data_ptr() if c.get('wf') is not None else None)
         self._convs = (L.ConvWeights * len(w.convs))(*[mk(c) for c in w.convs])
         self._stage_tab = (C.c_void_p * (num_stages * L.SW_COUNT))(*[st[k].data_ptr() for st in w.stages for k in L.STAGE_KEYS])
         self._gaze_tab = _table(w.gaze, L.GAZE_KEYS)

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('MCGAZE_LIB') or os.path.join(_HERE, 'libmcgaze_hip.so
 
 MCG_OK = 0
 MCG_F32, MCG_BF16, MCG_BF16X3 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 RES_NONE, RES_ADD, RES_UPSAMPLE_ADD = 0, 1, 2
 FLAG_STAGED_GEMM, FLAG_NO_SPECIALISED = 1, 2
 
@@ -43,7 +43,7 @@ class ConvDesc(C.Structure):
 
 class ConvWeights(C.Structure):
     _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('k', C.c_int),
-                ('stride', C.c_int), ('pad', C.c_int)]
+                ('stride', C.c_int), ('pad', C.c_int), ('wf', C.c_void_p)]
 
 
 class ModelWeights(C.Structure):

@@ -49,15 +49,15 @@ def ohwi(w):
 
 
 def frag_major(w):
-    """[..., 32 nt out, 256 in] -> MFMA-fragment-major [..., t=nt][ks=16][lane=64][e=8] with
-    WF[t][ks][lane][e] = W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e] (include/mcgaze_hip.h, MCG_SW_*_WF)."""
+    """[..., 32 nt out, 16 nk in] -> MFMA-fragment-major [..., t=nt][ks=nk][lane=64][e=8] with
+    WF[t][ks][lane][e] = W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e] (include/mcgaze_hip.h: MCG_SW_*_WF, mcg_conv_weights.wf)."""
     lead = w.shape[:-2]
-    rows = w.shape[-2]
-    assert w.shape[-1] == 256 and rows % 32 == 0
-    v = w.reshape(*lead, rows // 32, 32, 16, 2, 8)             # t, n, ks, half, e
+    rows, K = w.shape[-2:]
+    assert K % 16 == 0 and rows % 32 == 0, (rows, K)
+    v = w.reshape(*lead, rows // 32, 32, K // 16, 2, 8)        # t, n, ks, half, e
     n = len(lead)
     v = v.permute(*range(n), n, n + 2, n + 3, n + 1, n + 4)    # t, ks, half, n, e  -> lane = 32 half + n
-    return v.contiguous().reshape(*lead, rows, 256)
+    return v.contiguous().reshape(*lead, rows, K)
 
 
 def split_pack(w):
@@ -99,6 +99,8 @@ class PackedWeights:
         mat = (lambda t: self._dev(split_pack(t))) if split else (lambda t: self._dev(t.to(dtype)))               # [..., out, in]
         cmat = (lambda t: self._dev(split_pack(t.reshape(t.shape[0], -1)))) if split else mat                      # OHWI conv weight
         vec = lambda t: self._dev(t.float())
+        # fragment-major copies of the 1x1 convs (bf16 engine): operands of the fused conv3 -> next conv1 kernel (pw_pair.hpp)
+        wf1x1 = (lambda w: self._dev(frag_major(w.reshape(w.shape[0], -1).to(dtype)))) if dtype == torch.bfloat16 else (lambda w: None)
 
         w, b = fold_bn(sd, 'backbone.conv1.weight', 'backbone.bn1')
         stem = torch.zeros(64, 7, 8, 4)
@@ -112,14 +114,15 @@ class PackedWeights:
                 stride = 2 if (bi == 0 and li > 0) else 1
                 for conv, bn, k, s, pad in (('conv1', 'bn1', 1, 1, 0), ('conv2', 'bn2', 3, stride, 1), ('conv3', 'bn3', 1, 1, 0)):
                     w, b = fold_bn(sd, f'{p}.{conv}.weight', f'{p}.{bn}')
-                    self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=k, stride=s, pad=pad))
+                    self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=k, stride=s, pad=pad, wf=wf1x1(w) if k == 1 else None))
                 if f'{p}.downsample.0.weight' in sd:
                     w3, b3 = w, b  # conv3 of this block (last of the loop above)
                     w, b = fold_bn(sd, f'{p}.downsample.0.weight', f'{p}.downsample.1')
                     self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=1, stride=stride, pad=0))
                     if fuse_downsample:
                         wcat = torch.cat([ohwi(w3), ohwi(w)], dim=3)  # [Cout,1,1,planes + inplanes]
-                        self.c3_ds.append(dict(w=cmat(wcat), bias=vec(b3 + b), cin=wcat.shape[3], cout=wcat.shape[0], k=1, stride=1, pad=0))
+                        self.c3_ds.append(dict(w=cmat(wcat), bias=vec(b3 + b), cin=wcat.shape[3], cout=wcat.shape[0], k=1, stride=1, pad=0,
+                                               wf=wf1x1(wcat.permute(0, 3, 1, 2))))
         self.lateral, self.fpn_out = [], []
         for i in range(4):
             w = sd[f'neck.lateral_convs.{i}.conv.weight']

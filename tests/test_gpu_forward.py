@@ -372,3 +372,22 @@ def test_graphed_forward_is_bit_identical(engines, precision):
     torch.cuda.synchronize()
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+def test_pointwise_pair_fusion_is_bit_identical(engines):
+    """pw_pair.hpp (layer1 / layer2: a block's conv3 (+ downsample / + residual) and the next block's conv1 as one kernel) against
+    the layer-granular launches: the pyramid -- hence everything downstream -- must not change by a bit, on frame sizes whose
+    pixel counts are and are not multiples of the kernel's 64-pixel tile."""
+    e = engines['bf16']
+    try:
+        for shape in ((3, 224, 224), (2, 96, 160), (5, 32, 32), (1, 448, 448)):
+            img = torch.from_numpy(synth.make_clips(61, 1, *shape)).to('cuda:0')
+            e.set_option('pointwise_pair', 0)
+            ref = [p.clone() for p in e.backbone_fpn(img)]
+            e.set_option('pointwise_pair', 1)
+            out = e.backbone_fpn(img)
+            torch.cuda.synchronize()
+            for lvl, (a, b) in enumerate(zip(ref, out)):
+                assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (shape, lvl)
+    finally:
+        e.set_option('pointwise_pair', 1)

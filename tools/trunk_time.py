@@ -1,13 +1,24 @@
-"""GPU tool: trunk-only (backbone + FPN) step time for several frame-chunk sizes.  Usage: python tools/trunk_time.py [chunks...]"""
+"""GPU tool: trunk (backbone + FPN) time for 64 clips with an engine option off / on.
+usage: python tools/trunk_time.py [option=pointwise_pair] [precision=bf16]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mcgaze_amd import synth
 from mcgaze_amd.engine import HipEngine
-e = HipEngine(synth.make_state_dict(0), precision='bf16')
+
+opt = sys.argv[1] if len(sys.argv) > 1 else 'pointwise_pair'
+prec = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
+eng = HipEngine(synth.make_state_dict(0), precision=prec)
 img = torch.from_numpy(synth.make_clips(3, 64, 7)).cuda()
-for ch in [int(a) for a in sys.argv[1:]] or [0]:
-    for _ in range(5): e.backbone_fpn(img, ch)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20): e.backbone_fpn(img, ch)
-    torch.cuda.synchronize(); print(f'trunk only, chunk_frames={ch}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/step')
+for streams in (1, 2):
+    eng.set_option('trunk_streams', streams)
+    for val in (0, 1, 0, 1):
+        eng.set_option(opt, val)
+        for _ in range(3):
+            eng.backbone_fpn(img)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.backbone_fpn(img)
+        torch.cuda.synchronize()
+        print(f'trunk_streams={streams} {opt}={val}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms', flush=True)
