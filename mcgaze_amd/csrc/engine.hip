@@ -8,7 +8,6 @@
 // workgroups of one range's kernel (layer3 at 14x14 has 343 output tiles for 256 CUs) overlaps with the other range's
 // kernels: 448 frames 9.36 -> 8.75 ms (tools/trunk_two_streams.py).
 #include "igemm.hpp"
-#include "bottleneck_fused.hpp"
 #include "pw_pair.hpp"
 
 #include <stdlib.h>
@@ -45,7 +44,6 @@ struct mcg_engine {
   Prof prof;                   // per-launch event records (mcg_engine_profile_start / _stop)
   int trunk_streams = 2;       // concurrent frame ranges of the trunk
   int max_range_frames = 0;    // 0 = what fits the 2 GiB descriptor window
-  bool fused_block = false;    // experimental one-kernel layer1 identity bottleneck (bottleneck_fused.hpp)
   bool pw_pair = true;         // layer1 / layer2 (bf16): conv3 (+ residual) and the next block's conv1 as one kernel (pw_pair.hpp)
   std::mutex mu;               // one forward at a time per engine: the fork/join events and side streams are shared state
 };
@@ -185,7 +183,6 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "conv3x3_c64")) e->ctx.c64 = value != 0;
   else if (!strcmp(name, "stem_fused")) e->ctx.stem_fused = value != 0;
   else if (!strcmp(name, "decoder_chain")) e->ctx.chain = value != 0;
-  else if (!strcmp(name, "fused_bottleneck")) e->fused_block = value != 0;
   else if (!strcmp(name, "pointwise_pair")) e->pw_pair = value != 0;
   else { mcg_set_error("mcg_engine_set_option: unknown option '%s'", name); return MCG_ERR_ARG; }
   return MCG_OK;
@@ -298,17 +295,6 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
       const bool has_ds = b == 0;
       const int ho = (h + 2 * c2.pad - c2.k) / c2.stride + 1, wo = (w + 2 * c2.pad - c2.k) / c2.stride + 1;
       void* y = (b == e->blocks[l] - 1) ? (void*)t.c[l] : (x == t.xa ? (void*)t.xb : (void*)t.xa);
-      if (dt == MCG_BF16 && !has_ds && e->fused_block && c1.cin == 256 && c1.cout == 64 && c1.k == 1 && c2.cin == 64 && c2.cout == 64 &&
-          c2.k == 3 && c2.stride == 1 && c2.pad == 1 && c3.cin == 64 && c3.cout == 256 && c3.k == 1 && c1.bias && c2.bias && c3.bias) {
-        // identity bottleneck of layer1 as ONE kernel (bottleneck_fused.hpp): the 64-channel intermediates stay on the CU
-        if (launch_bottleneck_fused(s, x, y, c1.w, c1.bias, c2.w, c2.bias, c3.w, c3.bias, n, h, w)) {
-          mcg_set_error("bottleneck_fused launch failed");
-          return MCG_ERR_HIP;
-        }
-        x = y;
-        ci += 3;
-        continue;
-      }
       if (!o1_ready) MCG_TRY(conv_call(e, s, dt, c1, x, n, h, w, t.o1, 1, nullptr, MCG_RES_NONE, 0, 0));
       o1_ready = false;
       MCG_TRY(conv_call(e, s, dt, c2, t.o1, n, h, w, t.o2, 1, nullptr, MCG_RES_NONE, 0, 0));
@@ -328,7 +314,11 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
         pp.w3f = c3w->wf; pp.b3 = c3w->bias; pp.y = y;
         pp.w1f = c1n->wf; pp.b1 = c1n->bias; pp.z = t.o1;
         pp.M = n * ho * wo; pp.C = c3.cout; pp.C2 = c1n->cout; pp.Ho = ho; pp.Wo = wo;
-        if (launch_pw_pair(s, pp)) { mcg_set_error("pw_pair launch failed"); return MCG_ERR_HIP; }
+        // cfg 60: both contractions of the pair count (2 M (K C + C C2))
+        ProfRec* rec = prof_begin(e->ctx, s, 60, pp.M, pp.C + pp.C2, pp.K1 + pp.K2, 2.0 * pp.M * ((double)(pp.K1 + pp.K2) * pp.C + (double)pp.C * pp.C2));
+        const int prc = launch_pw_pair(s, pp);
+        prof_end(rec, s);
+        if (prc) { mcg_set_error("pw_pair launch failed"); return MCG_ERR_HIP; }
         o1_ready = true;
         x = y; h = ho; w = wo;
         ci = ci_next;

@@ -38,7 +38,7 @@ extern "C" int mcg_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int
 // Per-launch profiling of the contraction kernel (bench.py's roofline line): when the context carries an armed Prof, every
 // contraction launch is bracketed by a hipEvent pair on the launch stream and tagged with its algorithmic FLOPs
 // (2*M*Cout*K, true K for the zero-padded stem) and tile configuration.  The records belong to the engine (engine.hip).
-static ProfRec* prof_begin(const McgCtx& ctx, hipStream_t s, int cfg, int M, int N, int K, double flops) {
+ProfRec* prof_begin(const McgCtx& ctx, hipStream_t s, int cfg, int M, int N, int K, double flops) {
   Prof* pr = ctx.prof;
   if (!pr || pr->n >= pr->cap) return nullptr;
   ProfRec* rec = &pr->recs[pr->n++];
@@ -48,7 +48,7 @@ static ProfRec* prof_begin(const McgCtx& ctx, hipStream_t s, int cfg, int M, int
   (void)hipEventRecord(rec->a, s);
   return rec;
 }
-static void prof_end(ProfRec* rec, hipStream_t s) {
+void prof_end(ProfRec* rec, hipStream_t s) {
   if (rec) (void)hipEventRecord(rec->b, s);
 }
 static double algo_flops(const IgemmParams& p, int groups) {

@@ -283,6 +283,10 @@ struct McgCtx {
   }
 };
 
+// Profiling hooks (igemm.hip): bracket one launch with the context's event pair, tagged with a configuration id and its work.
+ProfRec* prof_begin(const McgCtx& ctx, hipStream_t s, int cfg, int M, int N, int K, double flops);
+void prof_end(ProfRec* rec, hipStream_t s);
+
 // Host-side launcher (igemm.hip).  Picks the tile shape from Cout / M.
 int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p, int groups, const McgCtx& ctx);
 // Convenience: y[M][Cout] = x[M][K] * w[Cout][K]^T (+bias)(+res)(relu), rows lda / ldy apart.
