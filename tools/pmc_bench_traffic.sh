@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob(f'{out}/{sub}/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
-            if 'igemm' in row['Kernel_Name']:
+            if 'igemm' in row['Kernel_Name'] or 'pw_pair' in row['Kernel_Name']:
                 agg[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
 res = {}
 for k, d in agg.items():
@@ -24,6 +24,8 @@ for k, d in agg.items():
     m = re.search(r'igemm_dma_kernel<float, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 1>', k)
     if m:
         name = f'igemm_dma_kernel<float,{",".join(m.groups())},x3>'
+    if 'pw_pair' in k:
+        name = 'pw_pair_kernel (conv3 + next conv1, layer1)'
     fetch = sum(d['FETCH_SIZE']) / max(len(d['FETCH_SIZE']), 1) * 1024 * 2   # KiB units; x2: gfx950 FETCH_SIZE counts 128-B requests as 64 B
     write = sum(d['WRITE_SIZE']) / max(len(d['WRITE_SIZE']), 1) * 1024
     e = res.setdefault(name, {'fetch_bytes_per_launch': 0, 'write_bytes_per_launch': 0, 'launches_sampled': 0})
