@@ -1,7 +1,7 @@
 """-m gpu: every C-ABI operator of libmcgaze_hip.so against the oracle (oracle/mcgaze_oracle.py,
 plain torch fp32 on the CPU) on the same seeded inputs.
 
-Tolerances: MCG_F32 mode uses f32 MFMA (exact f32 fma chains) -> only summation order differs
+Tolerances (see STAGE_TOL / GAZE_TOL / PYRAMID_TOL below: measured x 1.5): MCG_F32 mode uses f32 MFMA (exact f32 fma chains) -> only summation order differs
 from the CPU reference, 1e-4 relative to the tensor's scale.  MCG_BF16 mode rounds operands and
 stored activations to bf16 (8 mantissa bits): 2e-2 relative to the tensor's scale per operator.
 """
@@ -410,11 +410,24 @@ def test_roi_align_hip_equals_scalar_statement(eng):
     assert worst < 2e-5
 
 
-@pytest.mark.parametrize('dtype', DTYPES)
+KINDS = ['fp32', 'bf16x3', 'bf16']   # engine kinds of the whole-operator tests below
+KIND_DTYPE = {'fp32': torch.float32, 'bf16x3': torch.float32, 'bf16': torch.bfloat16}
+# Per-operator bounds as a fraction of the tensor's scale: measured worst case over the parametrised cases x 1.5 (printed by the tests).
+# fp32: only the summation order differs from the CPU reference.  bf16x3: operands carry 16-17 bits.  bf16: 8 bits on operands and
+# stored activations.
+STAGE_TOL = {'fp32': dict(obj=2e-6, cls=2e-6, boxes=1e-6),          # measured <= 1.0e-6 / 1.3e-6 / 5.7e-7
+             'bf16x3': dict(obj=2.5e-5, cls=2.5e-5, boxes=1.2e-5),  # measured <= 1.3e-5 / 1.4e-5 / 7.0e-6
+             'bf16': dict(obj=1.5e-2, cls=2e-2, boxes=6e-3)}        # measured <= 9.6e-3 / 1.3e-2 / 4.0e-3 (round 1 allowed 6e-2)
+GAZE_TOL = {'fp32': 2e-6, 'bf16x3': 4.5e-5, 'bf16': 4e-2}           # measured 1.1e-6 / 2.8e-5 / 2.7e-2 (absolute, unit vectors)
+PYRAMID_TOL = {'fp32': 4e-6, 'bf16x3': 3e-5, 'bf16': 1.7e-2}        # measured <= 2.6e-6 / 1.9e-5 / 1.13e-2 (round 1 allowed 5e-2)
+
+
+@pytest.mark.parametrize('kind', KINDS)
 @pytest.mark.parametrize('B,T', [(1, 7), (2, 3), (3, 1)])
-def test_decoder_stage(eng, sd, dtype, B, T):
+def test_decoder_stage(eng, sd, kind, B, T):
     from mcgaze_amd.packing import PackedWeights
-    pw = PackedWeights(sd, dtype=dtype)
+    dtype, split = KIND_DTYPE[kind], kind == 'bf16x3'
+    pw = PackedWeights(sd, dtype=dtype, split=split)
     N = B * T
     g = torch.Generator().manual_seed(100 + N)
     q = lambda t: t.to(dtype).float()
@@ -426,12 +439,12 @@ def test_decoder_stage(eng, sd, dtype, B, T):
         cls_r, delta_r, obj_r, inter = orc.stqi_stage(sd, s, q(roi), q(obj), T, return_intermediates=True)
         boxes_r = orc.delta2bbox(boxes.reshape(-1, 4), delta_r.reshape(-1, 4), stds=(0.5, 0.5, 1., 1.), clip_border=False).reshape(N, 3, 4)
         roi_dev = roi.permute(0, 2, 3, 1).reshape(N * 3, 49, 256).contiguous().to(dtype).to('cuda:0')
-        obj_o, boxes_o, cls_o = eng.stage_forward(pw.stages[s], roi_dev, obj.to(dtype).to('cuda:0'), boxes.to('cuda:0'), T)
+        obj_o, boxes_o, cls_o = eng.stage_forward(pw.stages[s], roi_dev, obj.to(dtype).to('cuda:0'), boxes.to('cuda:0'), T, split=split)
         torch.cuda.synchronize()
-        tol = 2e-4 if dtype == torch.float32 else 6e-2
-        assert scale_err(obj_o, obj_r) < tol, 'obj'
-        assert scale_err(cls_o, cls_r.squeeze(-1)) < tol, 'cls'
-        assert scale_err(boxes_o, boxes_r) < tol, 'boxes'
+        errs = dict(obj=scale_err(obj_o, obj_r), cls=scale_err(cls_o, cls_r.squeeze(-1)), boxes=scale_err(boxes_o, boxes_r))
+        print(f'decoder stage {s} {kind} B={B} T={T}: ' + ', '.join(f'{k} {v:.2e}' for k, v in errs.items()))
+        for k, v in errs.items():
+            assert v < STAGE_TOL[kind][k], (k, v)
 
 
 @pytest.mark.parametrize('B,T', [(1, 7), (5, 3), (11, 1), (2, 10), (1, 11), (64, 7)])
@@ -456,23 +469,24 @@ def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T):
         assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), name
 
 
-@pytest.mark.parametrize('dtype', DTYPES)
-def test_gaze_head(eng, sd, dtype):
+@pytest.mark.parametrize('kind', KINDS)
+def test_gaze_head(eng, sd, kind):
     from mcgaze_amd.packing import PackedWeights
-    pw = PackedWeights(sd, dtype=dtype)
+    dtype, split = KIND_DTYPE[kind], kind == 'bf16x3'
+    pw = PackedWeights(sd, dtype=dtype, split=split)
     obj = torch.randn(9, 3, 256, generator=torch.Generator().manual_seed(8))
     ref = orc.gaze_head(sd, 3, obj.to(dtype).float())
-    out = eng.gaze_head(pw.gaze, obj.to(dtype).to('cuda:0')).cpu()
+    out = eng.gaze_head(pw.gaze, obj.to(dtype).to('cuda:0'), split=split).cpu()
     torch.cuda.synchronize()
-    tol = 1e-4 if dtype == torch.float32 else 4e-2
-    for i, k in enumerate(('gaze_score', 'face_gaze_score', 'eyes_gaze_score', 'head_gaze_score')):
-        assert float((out[i] - ref[k]).abs().max()) < tol, k
+    worst = max(float((out[i] - ref[k]).abs().max()) for i, k in enumerate(('gaze_score', 'face_gaze_score', 'eyes_gaze_score', 'head_gaze_score')))
+    print(f'gaze head {kind}: max |d| = {worst:.2e}')
+    assert worst < GAZE_TOL[kind]
     assert torch.allclose(out.norm(dim=-1), torch.ones(4, 9), atol=1e-5)
 
 
-@pytest.mark.parametrize('dtype', DTYPES)
-def test_backbone_fpn(eng, sd, dtype):
-    e = eng.HipEngine(sd, precision='fp32' if dtype == torch.float32 else 'bf16')
+@pytest.mark.parametrize('kind', KINDS)
+def test_backbone_fpn(eng, sd, kind):
+    e = eng.HipEngine(sd, precision=kind)
     img = torch.from_numpy(synth.make_clips(21, 1, 3, 64, 96))
     with torch.no_grad():
         ref = orc.fpn(sd, orc.resnet(sd, img))
@@ -481,4 +495,6 @@ def test_backbone_fpn(eng, sd, dtype):
         torch.cuda.synchronize()
         for lvl, (p, r) in enumerate(zip(pyr, ref)):
             assert tuple(p.shape) == (r.shape[0], r.shape[2], r.shape[3], r.shape[1])
-            assert scale_err(p.permute(0, 3, 1, 2), r) < (2e-4 if dtype == torch.float32 else 5e-2), f'P{lvl + 2} chunk={chunk}'
+            err = scale_err(p.permute(0, 3, 1, 2), r)
+            print(f'pyramid P{lvl + 2} {kind} chunk={chunk}: {err:.2e} of scale')
+            assert err < PYRAMID_TOL[kind], f'P{lvl + 2} chunk={chunk}'
