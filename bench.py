@@ -67,7 +67,7 @@ def parse():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
     ap.add_argument('--parity-engine', default='bf16x3', choices=['bf16x3', 'fp32', 'none'],
                     help='second engine timed in the same run (the one that meets the 1e-3 parity tolerance); skipped when equal to --precision')
-    ap.add_argument('--parity-steps', type=int, default=0, help='timed steps of the parity engine (0 = max(5, steps // 4))')
+    ap.add_argument('--parity-steps', type=int, default=0, help='timed steps of the parity engine (0 = max(10, steps // 4))')
     ap.add_argument('--chunk-frames', type=int, default=0)
     ap.add_argument('--workload', default='full', choices=['full', 'backbone_fpn', 'backbone'],
                     help="'full' = BASELINE.json configs[2] (the metric's configuration); 'backbone_fpn' = configs[1], the trunk alone "
@@ -413,7 +413,7 @@ def main():
         pleg.drain()
         torch.cuda.synchronize(dev)
         proof = roofline_of(pleg.sample_kernels(), a.parity_engine) if a.kernel_events == 'sample' else None
-        psteps = a.parity_steps or max(5, a.steps // 4)
+        psteps = a.parity_steps or max(10, a.steps // 4)
         pel = pleg.timed(psteps, max(2, a.warmup // 3))
         pver = pleg.verify()
         pval = total_per_step * psteps / pel
