@@ -154,15 +154,30 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const T* __restrict__ roi,
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     constexpr int PAIRS = DI / (2 * EPC);
-#pragma unroll 8
-    for (int j = 0; j < PAIRS; ++j) {
-      const uint4 a = pv ? *(const uint4*)(ap + j * 2 * EPC) : make_uint4(0, 0, 0, 0);
-      const uint4 b = *(const uint4*)(bp + j * 2 * EPC);
-      Mma<T>::run(acc, a, b);
+    // all operand fragments of a group of K-steps are in flight together (one L2 latency per group, not one per step): the
+    // kernel is latency-bound -- every operand is used by one token only and comes straight from L2
+    constexpr int GRP = PAIRS < 8 ? PAIRS : 8;
+#pragma unroll
+    for (int j0 = 0; j0 < PAIRS; j0 += GRP) {
+      uint4 a[GRP], b[GRP];
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        a[j] = pv ? *(const uint4*)(ap + (j0 + j) * 2 * EPC) : make_uint4(0, 0, 0, 0);
+        b[j] = *(const uint4*)(bp + (j0 + j) * 2 * EPC);
+      }
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) Mma<T>::run(acc, a[j], b[j]);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) D1[(tm * 32 + mfma32_row(i, lane)) * D1_LD + tn * 32 + (lane & 31)] = acc[i];
   }
+  // stage 2's weight fragments (wave -> columns [wave*64, +64) of Wout^T, K = 64): issued now, consumed after the LayerNorm below
+  constexpr int PAIRS2 = DF / (2 * EPC);
+  uint4 bf2[PAIRS2][2];
+#pragma unroll
+  for (int j = 0; j < PAIRS2; ++j)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bf2[j][b] = *(const uint4*)(Wout + (long long)(wave * 64 + b * 32 + (lane & 31)) * DF + (2 * j + (lane >> 5)) * EPC);
   __syncthreads();
   // ---- LN over 64 features + ReLU, one wave per row, lane = feature; write F1 as dtype A operand
   for (int row = wave; row < 64; row += 4) {
@@ -196,10 +211,7 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const T* __restrict__ roi,
         af[a] = *(const uint4*)(A2 + row * A2_ROWB + ((ch ^ ((row / A2_RPB) % A2_CPR)) << 4));
       }
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int n = wave * 64 + b * 32 + (lane & 31);
-        bf[b] = *(const uint4*)(Wout + (long long)n * DF + ch * EPC);
-      }
+      for (int b = 0; b < 2; ++b) bf[b] = bf2[j][b];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
