@@ -48,15 +48,24 @@ struct PwPairParams {
 template <int NSRC, int C2T>   // NSRC: 1 = one 64-channel A source (identity block), 2 = two (block 0: conv2 output | downsample input)
 __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
   constexpr int PX = 64, YROWB = 512, AROWB = 128, KS1 = 4 * NSRC;
-  // LDS: NSRC == 1 (residual present): two buffers of [y / residual tile | A tile] = 2 x 40 KiB; NSRC == 2 (block 0, no residual):
-  // one y tile + two buffers of [A tile 1 | A tile 2] = 32 + 2 x 16 KiB.  Either way two workgroups fit a CU: with ONE tile of
-  // loads in flight per CU the kernel is latency-bound (bytes in flight / memory latency = 3.7 TB/s), with two it is not.
-  constexpr int YBUF = NSRC == 1 ? PX * YROWB + PX * AROWB : 0;   // stride of the y tile between the two buffers
-  constexpr int ABASE = NSRC == 1 ? PX * YROWB : PX * YROWB;      // A tiles start behind the (first) y tile
-  constexpr int ABUF = NSRC == 1 ? PX * YROWB + PX * AROWB : 2 * PX * AROWB;
+  // LDS.  NSRC == 1 (residual present): two y / residual tiles (the residual of the next tile lands while this one is used) + ONE A
+  // tile (consumed by the first contraction early in the iteration; the next tile's A rows are fetched right after it) = 72 KiB.
+  // NSRC == 2 (block 0, no residual): one y tile + two buffers of [A tile 1 | A tile 2] = 64 KiB.  + 1.5 KiB of biases.  Either way
+  // two workgroups fit a CU: with ONE tile of loads in flight per CU the kernel is latency-bound (bytes in flight / memory latency
+  // = 3.7 TB/s), with two it is not.
+  constexpr int YBUF = NSRC == 1 ? PX * YROWB : 0;                 // stride of the y tile between the two buffers
+  constexpr int ABASE = NSRC == 1 ? 2 * PX * YROWB : PX * YROWB;   // A tiles start behind the y tile(s)
+  constexpr int ABUF = NSRC == 1 ? 0 : 2 * PX * AROWB;             // stride of the A tiles between the two buffers (single A tile for NSRC == 1)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, px_l = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // biases live in LDS: a global load inside the tile loop would queue behind the next tile's DMA (loads return in order) and the
+  // compiler's wait for it would drain the prefetch before the epilogue could start
+  constexpr int TILES_BYTES = NSRC == 1 ? 2 * PX * YROWB + PX * AROWB : PX * YROWB + 2 * 2 * PX * AROWB;
+  float* s_b3 = (float*)(smem + TILES_BYTES);
+  float* s_b1 = s_b3 + 256;
+  for (int i = tid; i < 256; i += 256) s_b3[i] = p.b3[i];
+  for (int i = tid; i < p.C2; i += 256) s_b1[i] = p.b1[i];
   auto a_off = [](int px, int chunk) { return px * AROWB + ((chunk ^ ((px >> 1) & 7)) << 4); };
   auto y_off = [](int px, int chunk) { return px * YROWB + ((chunk ^ (px & 31)) << 4); };
   // ---- weight fragments, once per workgroup
@@ -92,16 +101,18 @@ __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
   }
   const int ntiles = (p.M + PX - 1) / PX;
   const bool has_res = p.res != nullptr;
-  auto issue = [&](int tile, uint32_t buf) {
+  auto issue_res = [&](int tile, uint32_t buf) {
     const int rows_left = p.M - tile * PX;                     // < 64 only on the last tile: rows beyond M read zeros (out-of-range offset)
-    const uint32_t so_res = (uint32_t)tile * (PX * YROWB), so_a = (uint32_t)tile * (PX * AROWB);
-    if (has_res) {
-      static_for<8>([&](auto jc) {
-        constexpr int J = decltype(jc)::value;
-        const int row = (wave * 8 + J) * 2 + (lane >> 5);
-        lds_dma16<J * 1024>(row < rows_left ? vres[J] : MCG_OOB_OFFSET, srd_res, so_res, lds_base + buf * YBUF + wave * 8192);
-      });
-    }
+    const uint32_t so_res = (uint32_t)tile * (PX * YROWB);
+    static_for<8>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const int row = (wave * 8 + J) * 2 + (lane >> 5);
+      lds_dma16<J * 1024>(row < rows_left ? vres[J] : MCG_OOB_OFFSET, srd_res, so_res, lds_base + buf * YBUF + wave * 8192);
+    });
+  };
+  auto issue_a = [&](int tile, uint32_t buf) {
+    const int rows_left = p.M - tile * PX;
+    const uint32_t so_a = (uint32_t)tile * (PX * AROWB);
     static_for<2>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
       const int row = (wave * 2 + J) * 8 + (lane >> 3);
@@ -112,14 +123,21 @@ __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
   };
   const int zrowb = p.C2 * 2, zc = p.C2 / 8;
   int it = 0;
-  if ((int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
+  if ((int)blockIdx.x < ntiles) {
+    if (has_res) issue_res(blockIdx.x, 0);
+    issue_a(blockIdx.x, 0);
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
     const long long m0 = (long long)tile * PX;
     char* s_y = smem + (it & 1) * YBUF;
     const char* s_a = smem + ABASE + (it & 1) * ABUF;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of the tile have landed (and its earlier stores left)
     __syncthreads();                                           // everyone's pieces landed; everyone is done with the other buffer
-    if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, (it + 1) & 1);
+    const bool more = tile + (int)gridDim.x < ntiles;
+    if (more) {
+      if (has_res) issue_res(tile + gridDim.x, (it + 1) & 1);
+      if constexpr (NSRC == 2) issue_a(tile + gridDim.x, (it + 1) & 1);   // double-buffered A tiles; NSRC == 1: after the first contraction
+    }
     // ---- first contraction: wave -> channel tiles {2 wave, 2 wave + 1} x both pixel tiles, K ascending (source 1, then source 2)
     f32x16 acc[2][2];
 #pragma unroll
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c0 = (wave * 2 + i) * 32 + 8 * q + 4 * half;
-        const float4 b4 = *(const float4*)(p.b3 + c0);
+        const float4 b4 = *(const float4*)(s_b3 + c0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int px = j * 32 + px_l;
@@ -159,7 +177,10 @@ __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
         }
       }
     }
-    __syncthreads();                                           // y tile complete
+    __syncthreads();                                           // y tile complete; the A tile has been consumed by every wave
+    if constexpr (NSRC == 1) {
+      if (more) issue_a(tile + gridDim.x, 0);                  // single A tile: refill it now
+    }
     // ---- y -> global (coalesced rows) and second contraction (K = the 256 channels of y)
     for (int idx = tid; idx < PX * 32; idx += 256) {
       const int px = idx >> 5, c = idx & 31;
@@ -186,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c0 = ct2 * 32 + 8 * q + 4 * half;
-        const float4 b4 = *(const float4*)(p.b1 + c0);
+        const float4 b4 = *(const float4*)(s_b1 + c0);
         const float v[4] = {acc2[t][4 * q] + b4.x, acc2[t][4 * q + 1] + b4.y, acc2[t][4 * q + 2] + b4.z, acc2[t][4 * q + 3] + b4.w};
         *(uint2*)(s_y + px * zrowb + (((c0 >> 3) ^ (px & 7)) << 4) + (c0 & 7) * 2) = relu_pack4(v);
       }
@@ -206,7 +227,7 @@ static inline bool pw_pair_applicable(int K1, int K2, int stride2, int C, int C2
 }
 template <int NSRC, int C2T>
 static inline void launch_pw_pair_t(hipStream_t s, const PwPairParams& p) {
-  constexpr int kLds = NSRC == 1 ? 2 * (64 * 512 + 64 * 128) : 64 * 512 + 2 * 2 * 64 * 128;
+  constexpr int kLds = (NSRC == 1 ? 2 * 64 * 512 + 64 * 128 : 64 * 512 + 2 * 2 * 64 * 128) + (256 + 128) * 4;
   static int cus = 0;
   if (!cus) {
     int dev = 0;
