@@ -9,6 +9,7 @@
 // kernels: 448 frames 9.36 -> 8.75 ms (tools/trunk_two_streams.py).
 #include "igemm.hpp"
 #include "pw_pair.hpp"
+#include "pw_single.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -44,6 +45,7 @@ struct mcg_engine {
   Prof prof;                   // per-launch event records (mcg_engine_profile_start / _stop)
   int trunk_streams = 2;       // concurrent frame ranges of the trunk
   int max_range_frames = 0;    // 0 = what fits the 2 GiB descriptor window
+  bool pw_single = true;       // HBM-bound 1x1 convs of layer2 / the P2 lateral (bf16): persistent register-resident-weight kernel (pw_single.hpp)
   bool pw_pair = true;         // layer1 / layer2 (bf16): conv3 (+ residual) and the next block's conv1 as one kernel (pw_pair.hpp)
   std::mutex mu;               // one forward at a time per engine: the fork/join events and side streams are shared state
 };
@@ -184,6 +186,7 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "stem_fused")) e->ctx.stem_fused = value != 0;
   else if (!strcmp(name, "decoder_chain")) e->ctx.chain = value != 0;
   else if (!strcmp(name, "pointwise_pair")) e->pw_pair = value != 0;
+  else if (!strcmp(name, "pointwise_stream")) e->pw_single = value != 0;
   else { mcg_set_error("mcg_engine_set_option: unknown option '%s'", name); return MCG_ERR_ARG; }
   return MCG_OK;
 }
@@ -276,6 +279,21 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
   d.x = x; d.w = cw.w; d.bias = cw.bias; d.residual = res; d.y = y;
   d.N = n; d.H = h; d.W = w; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.k; d.KW = cw.k; d.stride = cw.stride; d.pad = cw.pad;
   d.relu = relu; d.residual_mode = res_mode; d.Hr = hr; d.Wr = wr;
+  const long long M = (long long)n * h * w;
+  const int rm = res ? res_mode : MCG_RES_NONE;
+  if (dt == MCG_BF16 && e->pw_single && e->ctx.tile < 0 && !e->ctx.staged && cw.wf && cw.bias && cw.k == 1 && cw.stride == 1 && cw.pad == 0 &&
+      pw_single_applicable(cw.cin, cw.cout, rm, M, rm == MCG_RES_UPSAMPLE_ADD ? (long long)n * hr * wr : M) && M < 0x7fffffffll) {
+    PwSingleParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.a = x; pp.res = res; pp.wf = cw.wf; pp.bias = cw.bias; pp.y = y;
+    pp.M = (int)M; pp.relu = relu; pp.Ho = h; pp.Wo = w;
+    if (rm == MCG_RES_UPSAMPLE_ADD) { pp.Hr = hr; pp.Wr = wr; pp.rscale_h = (float)hr / (float)h; pp.rscale_w = (float)wr / (float)w; }
+    ProfRec* rec = prof_begin(e->ctx, s, 61, pp.M, cw.cout, cw.cin, 2.0 * M * cw.cin * cw.cout);
+    const int prc = launch_pw_single(s, pp, cw.cin, cw.cout, rm == MCG_RES_NONE ? 0 : (rm == MCG_RES_ADD ? 1 : 2));
+    prof_end(rec, s);
+    if (prc) { mcg_set_error("pw_single launch failed"); return MCG_ERR_HIP; }
+    return MCG_OK;
+  }
   return conv2d_ctx(s, dt, &d, e->ctx);
 }
 

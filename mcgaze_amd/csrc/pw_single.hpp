@@ -1,0 +1,176 @@
+// HBM-bound 1x1 convolutions of the bf16 trunk (layer2's conv1 512 -> 128 and conv3 128 -> 512 + residual, the FPN lateral 256 -> 256
+// + nearest-upsampled top-down term) as a persistent streaming kernel -- pw_pair.hpp's structure with one contraction:
+//
+//     y = [relu]( A . W^T + b (+ res | + up(res)) )        A [M][K], W [N][K], N * K * 2 B <= 128 KB
+//
+// The generic contraction kernel runs these at 3.2-4.6 TB/s (a fresh prologue / epilogue per 256-row tile, K of 2-8 K-tiles); here a
+// workgroup keeps the whole weight matrix in REGISTERS (128 VGPRs per wave), walks 32-pixel tiles with a grid-stride loop, and the
+// next tile's A rows and residual rows travel HBM -> LDS by `buffer_load ... lds` while the current tile is contracted and stored:
+// two workgroups per CU, no global load inside the loop other than those DMAs (biases sit in LDS -- a load queued behind the next
+// tile's DMA would drain the prefetch, pw_pair.hpp), transposed MFMAs so that bias / residual / ReLU / bf16 rounding work on 8-byte
+// pieces in the LDS tile that the coalesced store reads.  K order and rounding points are the generic kernel's: bit-identical.
+#pragma once
+#include "pw_pair.hpp"
+
+struct PwSingleParams {
+  const void* a;            // [M][K] bf16, rows contiguous
+  const void* res;          // RES 1: [M][N]; RES 2: [frames][Hr][Wr][N] gathered at (y * Hr / Ho, x * Wr / Wo) (F.interpolate nearest)
+  const void* wf;           // [N/32][K/16][64][8] fragment-major
+  const float* bias;        // [N]
+  void* y;                  // [M][N]
+  int M, relu, Ho, Wo, Hr, Wr;
+  float rscale_h, rscale_w;
+};
+
+template <int KS, int TPW, int RES>   // K = 16 KS; N = 128 TPW (TPW 32-channel tiles per wave, 4 waves); RES: 0 none, 1 same-shape add, 2 nearest-upsample add
+__global__ __launch_bounds__(256, 2) void pw_single_kernel(const PwSingleParams p) {
+  constexpr int PX = 32, K = 16 * KS, N = 128 * TPW, AROWB = 2 * K, YROWB = 2 * N, ACH = AROWB / 16, YCH = YROWB / 16;
+  constexpr int ABYTES = PX * AROWB, YBYTES = PX * YROWB;
+  constexpr int NYB = RES ? 2 : 1;                                           // y / residual tiles (the residual of the next tile lands early)
+  constexpr int NAB = (2 * ABYTES + NYB * YBYTES + N * 4 <= 80 * 1024) ? 2 : 1;   // A tiles: double-buffered when two workgroups still fit a CU
+  constexpr int AOFF = NYB * YBYTES, BOFF = AOFF + NAB * ABYTES;
+  constexpr int A_PIECES = ABYTES / 1024 / 4, Y_PIECES = YBYTES / 1024 / 4;   // 1 KiB DMA pieces per wave
+  static_assert(A_PIECES >= 1 && Y_PIECES >= 1, "tile geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_bias = (float*)(smem + BOFF);
+  const int tid = threadIdx.x, lane = tid & 63, px = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < N; i += 256) s_bias[i] = p.bias[i];
+  auto a_off = [](int r, int chunk) { return r * AROWB + ((chunk ^ (r & (ACH >= 32 ? 31 : 15))) << 4); };
+  auto y_off = [](int r, int chunk) { return r * YROWB + ((chunk ^ (r & (YCH >= 32 ? 31 : 15))) << 4); };
+  // ---- weights, once per workgroup: wave -> channel tiles wave * TPW + i
+  uint4 w[TPW][KS];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const char* wb = (const char*)p.wf + ((size_t)(wave * TPW + i) * KS * 64 + lane) * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) w[i][ks] = *(const uint4*)(wb + (size_t)ks * 1024);
+  }
+  // ---- DMA geometry: lane-linear on the LDS side, XOR swizzle on the source chunk; rows per 1 KiB piece = 1024 / row bytes
+  const u32x4 srd_a = make_srd(p.a), srd_r = make_srd(RES ? p.res : p.a);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  constexpr int A_LPR = ACH < 64 ? ACH : 64, Y_LPR = YCH < 64 ? YCH : 64;     // lanes per row within a piece
+  constexpr int A_RPP = 64 / A_LPR, Y_RPP = 64 / Y_LPR;                       // rows per piece (1 KiB = 64 chunks)
+  static_assert(ACH <= 64 && YCH <= 64, "rows longer than 1 KiB are not laid out here");
+  const int ntiles = (p.M + PX - 1) / PX;
+  auto issue_a = [&](int tile, int buf) {
+    const int rows_left = p.M - tile * PX;
+    const uint32_t so = (uint32_t)tile * ABYTES;
+    static_for<A_PIECES>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const int row = (wave * A_PIECES + J) * A_RPP + lane / A_LPR, pos = lane % A_LPR;
+      const uint32_t vo = row < rows_left ? (uint32_t)(row * AROWB + ((pos ^ (row & (ACH >= 32 ? 31 : 15))) << 4)) : MCG_OOB_OFFSET;
+      lds_dma16<AOFF + J * 1024>(vo, srd_a, so, lds_base + buf * ABYTES + wave * (A_PIECES * 1024));
+    });
+  };
+  const int HoWo = p.Ho * p.Wo;
+  auto issue_res = [&](int tile, int buf) {
+    const int rows_left = p.M - tile * PX;
+    static_for<Y_PIECES>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const int row = (wave * Y_PIECES + J) * Y_RPP + lane / Y_LPR, pos = lane % Y_LPR;
+      const int chunk = pos ^ (row & (YCH >= 32 ? 31 : 15));
+      uint32_t vo = MCG_OOB_OFFSET, so = 0;
+      if (RES == 1) {
+        so = (uint32_t)tile * YBYTES;
+        if (row < rows_left) vo = (uint32_t)(row * YROWB + (chunk << 4));
+      } else if (row < rows_left) {   // nearest-upsample gather: source row of output pixel m (torch: src = min(floor(dst * in / out), in - 1))
+        const int m = tile * PX + row;
+        const int f = m / HoWo, rem = m - f * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int sh = min((int)floorf(ho * p.rscale_h), p.Hr - 1), sw = min((int)floorf(wo * p.rscale_w), p.Wr - 1);
+        vo = (uint32_t)((((long long)f * p.Hr + sh) * p.Wr + sw) * YROWB + (chunk << 4));
+      }
+      lds_dma16<J * 1024>(vo, srd_r, so, lds_base + buf * YBYTES + wave * (Y_PIECES * 1024));
+    });
+  };
+  if ((int)blockIdx.x < ntiles) {
+    if (RES) issue_res(blockIdx.x, 0);
+    issue_a(blockIdx.x, 0);
+  }
+  __syncthreads();   // biases in LDS
+  int it = 0;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+    const long long m0 = (long long)tile * PX;
+    char* s_y = smem + (RES ? (it & 1) * YBYTES : 0);
+    const char* s_a = smem + AOFF + (NAB == 2 ? (it & 1) * ABYTES : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of the tile have landed (and its earlier stores left)
+    __syncthreads();                                           // everyone's pieces landed; the other buffers are free
+    const bool more = tile + (int)gridDim.x < ntiles;
+    if (more) {
+      if (RES) issue_res(tile + gridDim.x, (it + 1) & 1);
+      if (NAB == 2) issue_a(tile + gridDim.x, (it + 1) & 1);
+    }
+    // ---- contraction: wave -> TPW channel tiles x one pixel tile, K ascending
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint4 x = *(const uint4*)(s_a + a_off(px, 2 * ks + half));
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) Mma<bf16_t>::run(acc[i], w[i][ks], x);
+    }
+    if (RES == 0) __syncthreads();                             // previous tile's y staging fully stored (single y tile)
+    // ---- epilogue: (acc + bias) (+ res) -> [relu] -> bf16, 8 bytes (4 channels of one pixel) at a time, into the y tile
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = (wave * TPW + i) * 32 + 8 * q + 4 * half;
+        const float4 b4 = *(const float4*)(s_bias + c0);
+        char* slot = s_y + y_off(px, c0 >> 3) + (c0 & 7) * 2;
+        float v[4] = {acc[i][4 * q] + b4.x, acc[i][4 * q + 1] + b4.y, acc[i][4 * q + 2] + b4.z, acc[i][4 * q + 3] + b4.w};
+        if (RES) {
+          const uint2 rr = *(const uint2*)slot;
+          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+        }
+        *(uint2*)slot = p.relu ? relu_pack4(v) : make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+    }
+    __syncthreads();                                           // y tile complete; the A tile has been consumed by every wave
+    if (NAB == 1 && more) issue_a(tile + gridDim.x, 0);        // single A tile: refill it now
+    for (int idx = tid; idx < PX * YCH; idx += 256) {
+      const int r = idx / YCH, c = idx - r * YCH;
+      if (m0 + r < p.M) *(uint4*)((bf16_t*)p.y + (m0 + r) * N + c * 8) = *(const uint4*)(s_y + y_off(r, c));
+    }
+  }
+}
+
+// (K, N) pairs of the R-50 trunk whose weights fit the registers of one workgroup (N * K * 2 B = 128 KB)
+static inline bool pw_single_applicable(int K, int N, int res_mode, long long M, long long res_rows) {
+  const bool shape = (K == 256 && N == 256) || (K == 512 && N == 128 && res_mode == 0) || (K == 128 && N == 512);
+  return shape && M >= 64 * 1024 && M * 2 * (K > N ? K : N) < MCG_DMA_MAX_BYTES && res_rows * 2 * N < MCG_DMA_MAX_BYTES;
+}
+template <int KS, int TPW, int RES>
+static inline void launch_pw_single_t(hipStream_t s, const PwSingleParams& p) {
+  constexpr int K = 16 * KS, N = 128 * TPW, AB = 32 * 2 * K, YB = 32 * 2 * N, NYB = RES ? 2 : 1;
+  constexpr int NAB = (2 * AB + NYB * YB + N * 4 <= 80 * 1024) ? 2 : 1;
+  constexpr int kLds = NYB * YB + NAB * AB + N * 4;
+  static_assert(kLds <= 80 * 1024, "two workgroups per CU");
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    (void)hipFuncSetAttribute((const void*)pw_single_kernel<KS, TPW, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+  }
+  const int ntiles = (p.M + 31) / 32, wgs = 2 * cus;
+  hipLaunchKernelGGL((pw_single_kernel<KS, TPW, RES>), dim3(ntiles < wgs ? ntiles : wgs), dim3(256), kLds, s, p);
+}
+static inline int launch_pw_single(hipStream_t s, const PwSingleParams& p, int K, int N, int res_mode) {
+  if (K == 256 && N == 256) {
+    if (res_mode == 0) launch_pw_single_t<16, 2, 0>(s, p);
+    else if (res_mode == 1) launch_pw_single_t<16, 2, 1>(s, p);
+    else launch_pw_single_t<16, 2, 2>(s, p);
+  } else if (K == 512 && N == 128) {
+    launch_pw_single_t<32, 1, 0>(s, p);
+  } else {
+    if (res_mode == 0) launch_pw_single_t<8, 4, 0>(s, p);
+    else if (res_mode == 1) launch_pw_single_t<8, 4, 1>(s, p);
+    else launch_pw_single_t<8, 4, 2>(s, p);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}

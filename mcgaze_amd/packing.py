@@ -99,7 +99,7 @@ class PackedWeights:
         mat = (lambda t: self._dev(split_pack(t))) if split else (lambda t: self._dev(t.to(dtype)))               # [..., out, in]
         cmat = (lambda t: self._dev(split_pack(t.reshape(t.shape[0], -1)))) if split else mat                      # OHWI conv weight
         vec = lambda t: self._dev(t.float())
-        # fragment-major copies of the 1x1 convs (bf16 engine): operands of the fused conv3 -> next conv1 kernel (pw_pair.hpp)
+        # fragment-major copies of the 1x1 convs (bf16 engine): operands of the register-resident-weight kernels (pw_pair.hpp, pw_single.hpp)
         wf1x1 = (lambda w: self._dev(frag_major(w.reshape(w.shape[0], -1).to(dtype)))) if dtype == torch.bfloat16 else (lambda w: None)
 
         w, b = fold_bn(sd, 'backbone.conv1.weight', 'backbone.bn1')
@@ -126,7 +126,7 @@ class PackedWeights:
         self.lateral, self.fpn_out = [], []
         for i in range(4):
             w = sd[f'neck.lateral_convs.{i}.conv.weight']
-            self.lateral.append(dict(w=cmat(ohwi(w)), bias=vec(sd[f'neck.lateral_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=1, stride=1, pad=0))
+            self.lateral.append(dict(w=cmat(ohwi(w)), bias=vec(sd[f'neck.lateral_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=1, stride=1, pad=0, wf=wf1x1(w)))
             w = sd[f'neck.fpn_convs.{i}.conv.weight']
             self.fpn_out.append(dict(w=cmat(ohwi(w)), bias=vec(sd[f'neck.fpn_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=3, stride=1, pad=1))
         self.init_boxes = vec(sd['rpn_head.init_proposal_bboxes.weight'])
