@@ -22,12 +22,16 @@ struct PwSingleParams {
   float rscale_h, rscale_w;
 };
 
-template <int KS, int TPW, int RES>   // K = 16 KS; N = 128 TPW (TPW 32-channel tiles per wave, 4 waves); RES: 0 none, 1 same-shape add, 2 nearest-upsample add
+// K = 16 KS; a workgroup owns N = 128 TPW output channels (TPW 32-channel tiles per wave, 4 waves) of the NSPLIT * N the layer has:
+// NSPLIT workgroups on one XCD (one L2) walk the same pixel tiles, each with its own slice of the weights in registers -- the A tile
+// comes from HBM once and from L2 for the others.  RES: 0 none, 1 same-shape add, 2 nearest-upsample add.
+template <int KS, int TPW, int RES, int NSPLIT>
 __global__ __launch_bounds__(256, 2) void pw_single_kernel(const PwSingleParams p) {
-  constexpr int PX = 32, K = 16 * KS, N = 128 * TPW, AROWB = 2 * K, YROWB = 2 * N, ACH = AROWB / 16, YCH = YROWB / 16;
+  constexpr int PX = 32, K = 16 * KS, N = 128 * TPW, NF = N * NSPLIT, AROWB = 2 * K, YROWB = 2 * N, GROWB = 2 * NF, ACH = AROWB / 16, YCH = YROWB / 16;
   constexpr int ABYTES = PX * AROWB, YBYTES = PX * YROWB;
   constexpr int NYB = RES ? 2 : 1;                                           // y / residual tiles (the residual of the next tile lands early)
-  constexpr int NAB = (2 * ABYTES + NYB * YBYTES + N * 4 <= 80 * 1024) ? 2 : 1;   // A tiles: double-buffered when two workgroups still fit a CU
+  constexpr bool BIAS_REGS = TPW == 1;                                       // one channel tile per wave: its 16 biases stay in registers (read before any DMA)
+  constexpr int NAB = (2 * ABYTES + NYB * YBYTES + (BIAS_REGS ? 0 : N * 4) <= 80 * 1024) ? 2 : 1;   // A tiles: double-buffered when two workgroups still fit a CU
   constexpr int AOFF = NYB * YBYTES, BOFF = AOFF + NAB * ABYTES;
   constexpr int A_PIECES = ABYTES / 1024 / 4, Y_PIECES = YBYTES / 1024 / 4;   // 1 KiB DMA pieces per wave
   static_assert(A_PIECES >= 1 && Y_PIECES >= 1, "tile geometry");
@@ -35,14 +39,22 @@ __global__ __launch_bounds__(256, 2) void pw_single_kernel(const PwSingleParams 
   float* s_bias = (float*)(smem + BOFF);
   const int tid = threadIdx.x, lane = tid & 63, px = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < N; i += 256) s_bias[i] = p.bias[i];
+  // blockIdx -> (walker, channel slice): ids 8 apart sit on the same XCD (round-robin dispatch over the 8 XCDs)
+  const int bid = blockIdx.x, nsp = (bid >> 3) % NSPLIT, walker = (bid / (8 * NSPLIT)) * 8 + (bid & 7), nwalkers = gridDim.x / NSPLIT;
+  float4 breg[4];
+  if constexpr (BIAS_REGS) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) breg[q] = *(const float4*)(p.bias + nsp * N + wave * 32 + 8 * q + 4 * (lane >> 5));
+  } else {
+    for (int i = tid; i < N; i += 256) s_bias[i] = p.bias[nsp * N + i];
+  }
   auto a_off = [](int r, int chunk) { return r * AROWB + ((chunk ^ (r & (ACH >= 32 ? 31 : 15))) << 4); };
   auto y_off = [](int r, int chunk) { return r * YROWB + ((chunk ^ (r & (YCH >= 32 ? 31 : 15))) << 4); };
   // ---- weights, once per workgroup: wave -> channel tiles wave * TPW + i
   uint4 w[TPW][KS];
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const char* wb = (const char*)p.wf + ((size_t)(wave * TPW + i) * KS * 64 + lane) * 16;
+    const char* wb = (const char*)p.wf + ((size_t)((nsp * 4 + wave) * TPW + i) * KS * 64 + lane) * 16;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) w[i][ks] = *(const uint4*)(wb + (size_t)ks * 1024);
   }
@@ -72,33 +84,33 @@ __global__ __launch_bounds__(256, 2) void pw_single_kernel(const PwSingleParams 
       const int chunk = pos ^ (row & (YCH >= 32 ? 31 : 15));
       uint32_t vo = MCG_OOB_OFFSET, so = 0;
       if (RES == 1) {
-        so = (uint32_t)tile * YBYTES;
-        if (row < rows_left) vo = (uint32_t)(row * YROWB + (chunk << 4));
+        so = (uint32_t)tile * (PX * GROWB) + nsp * YROWB;
+        if (row < rows_left) vo = (uint32_t)(row * GROWB + (chunk << 4));
       } else if (row < rows_left) {   // nearest-upsample gather: source row of output pixel m (torch: src = min(floor(dst * in / out), in - 1))
         const int m = tile * PX + row;
         const int f = m / HoWo, rem = m - f * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
         const int sh = min((int)floorf(ho * p.rscale_h), p.Hr - 1), sw = min((int)floorf(wo * p.rscale_w), p.Wr - 1);
-        vo = (uint32_t)((((long long)f * p.Hr + sh) * p.Wr + sw) * YROWB + (chunk << 4));
+        vo = (uint32_t)((((long long)f * p.Hr + sh) * p.Wr + sw) * GROWB + nsp * YROWB + (chunk << 4));
       }
       lds_dma16<J * 1024>(vo, srd_r, so, lds_base + buf * YBYTES + wave * (Y_PIECES * 1024));
     });
   };
-  if ((int)blockIdx.x < ntiles) {
-    if (RES) issue_res(blockIdx.x, 0);
-    issue_a(blockIdx.x, 0);
+  if (walker < ntiles) {
+    if (RES) issue_res(walker, 0);
+    issue_a(walker, 0);
   }
-  __syncthreads();   // biases in LDS
+  __syncthreads();   // biases in LDS (the loop's first wait covers the register copies)
   int it = 0;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+  for (int tile = walker; tile < ntiles; tile += nwalkers, ++it) {
     const long long m0 = (long long)tile * PX;
     char* s_y = smem + (RES ? (it & 1) * YBYTES : 0);
     const char* s_a = smem + AOFF + (NAB == 2 ? (it & 1) * ABYTES : 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of the tile have landed (and its earlier stores left)
     __syncthreads();                                           // everyone's pieces landed; the other buffers are free
-    const bool more = tile + (int)gridDim.x < ntiles;
+    const bool more = tile + nwalkers < ntiles;
     if (more) {
-      if (RES) issue_res(tile + gridDim.x, (it + 1) & 1);
-      if (NAB == 2) issue_a(tile + gridDim.x, (it + 1) & 1);
+      if (RES) issue_res(tile + nwalkers, (it + 1) & 1);
+      if (NAB == 2) issue_a(tile + nwalkers, (it + 1) & 1);
     }
     // ---- contraction: wave -> TPW channel tiles x one pixel tile, K ascending
     f32x16 acc[TPW];
@@ -119,7 +131,8 @@ __global__ __launch_bounds__(256, 2) void pw_single_kernel(const PwSingleParams 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c0 = (wave * TPW + i) * 32 + 8 * q + 4 * half;
-        const float4 b4 = *(const float4*)(s_bias + c0);
+        float4 b4;
+        if constexpr (BIAS_REGS) b4 = breg[q]; else b4 = *(const float4*)(s_bias + c0);
         char* slot = s_y + y_off(px, c0 >> 3) + (c0 & 7) * 2;
         float v[4] = {acc[i][4 * q] + b4.x, acc[i][4 * q + 1] + b4.y, acc[i][4 * q + 2] + b4.z, acc[i][4 * q + 3] + b4.w};
         if (RES) {
@@ -131,46 +144,58 @@ __global__ __launch_bounds__(256, 2) void pw_single_kernel(const PwSingleParams 
       }
     }
     __syncthreads();                                           // y tile complete; the A tile has been consumed by every wave
-    if (NAB == 1 && more) issue_a(tile + gridDim.x, 0);        // single A tile: refill it now
+    if (NAB == 1 && more) issue_a(tile + nwalkers, 0);        // single A tile: refill it now
     for (int idx = tid; idx < PX * YCH; idx += 256) {
       const int r = idx / YCH, c = idx - r * YCH;
-      if (m0 + r < p.M) *(uint4*)((bf16_t*)p.y + (m0 + r) * N + c * 8) = *(const uint4*)(s_y + y_off(r, c));
+      if (m0 + r < p.M) *(uint4*)((bf16_t*)p.y + (m0 + r) * NF + nsp * N + c * 8) = *(const uint4*)(s_y + y_off(r, c));
     }
   }
 }
 
-// (K, N) pairs of the R-50 trunk whose weights fit the registers of one workgroup (N * K * 2 B = 128 KB)
+// (K, N) pairs of the R-50 trunk whose weights -- or a 128 / 256-channel slice of them -- fit the registers of one workgroup (128 KB)
 static inline bool pw_single_applicable(int K, int N, int res_mode, long long M, long long res_rows) {
-  const bool shape = (K == 256 && N == 256) || (K == 512 && N == 128 && res_mode == 0) || (K == 128 && N == 512);
+  const bool shape = (K == 256 && N == 256) || (K == 512 && N == 128 && res_mode == 0) || (K == 128 && N == 512) ||
+                     (K == 256 && N == 1024) || (K == 512 && N == 256 && res_mode != 1);
   return shape && M >= 64 * 1024 && M * 2 * (K > N ? K : N) < MCG_DMA_MAX_BYTES && res_rows * 2 * N < MCG_DMA_MAX_BYTES;
 }
-template <int KS, int TPW, int RES>
+template <int KS, int TPW, int RES, int NSPLIT>
 static inline void launch_pw_single_t(hipStream_t s, const PwSingleParams& p) {
   constexpr int K = 16 * KS, N = 128 * TPW, AB = 32 * 2 * K, YB = 32 * 2 * N, NYB = RES ? 2 : 1;
-  constexpr int NAB = (2 * AB + NYB * YB + N * 4 <= 80 * 1024) ? 2 : 1;
-  constexpr int kLds = NYB * YB + NAB * AB + N * 4;
+  constexpr int BB = TPW == 1 ? 0 : N * 4;
+  constexpr int NAB = (2 * AB + NYB * YB + BB <= 80 * 1024) ? 2 : 1;
+  constexpr int kLds = NYB * YB + NAB * AB + BB;
   static_assert(kLds <= 80 * 1024, "two workgroups per CU");
   static int cus = 0;
   if (!cus) {
     int dev = 0;
     hipDeviceProp_t prop;
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute((const void*)pw_single_kernel<KS, TPW, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    (void)hipFuncSetAttribute((const void*)pw_single_kernel<KS, TPW, RES, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
   }
-  const int ntiles = (p.M + 31) / 32, wgs = 2 * cus;
-  hipLaunchKernelGGL((pw_single_kernel<KS, TPW, RES>), dim3(ntiles < wgs ? ntiles : wgs), dim3(256), kLds, s, p);
+  const int ntiles = (p.M + 31) / 32, unit = 8 * NSPLIT;
+  int wgs = 2 * cus / unit * unit;                              // two workgroups per CU, whole groups of NSPLIT slices x 8 XCDs
+  const int need = (ntiles + 7) / 8 * unit;
+  if (wgs < unit) wgs = unit;
+  hipLaunchKernelGGL((pw_single_kernel<KS, TPW, RES, NSPLIT>), dim3(need < wgs ? need : wgs), dim3(256), kLds, s, p);
 }
 static inline int launch_pw_single(hipStream_t s, const PwSingleParams& p, int K, int N, int res_mode) {
   if (K == 256 && N == 256) {
-    if (res_mode == 0) launch_pw_single_t<16, 2, 0>(s, p);
-    else if (res_mode == 1) launch_pw_single_t<16, 2, 1>(s, p);
-    else launch_pw_single_t<16, 2, 2>(s, p);
+    if (res_mode == 0) launch_pw_single_t<16, 2, 0, 1>(s, p);
+    else if (res_mode == 1) launch_pw_single_t<16, 2, 1, 1>(s, p);
+    else launch_pw_single_t<16, 2, 2, 1>(s, p);
+  } else if (K == 256 && N == 1024) {
+    if (res_mode == 0) launch_pw_single_t<16, 2, 0, 4>(s, p);
+    else if (res_mode == 1) launch_pw_single_t<16, 2, 1, 4>(s, p);
+    else launch_pw_single_t<16, 2, 2, 4>(s, p);
   } else if (K == 512 && N == 128) {
-    launch_pw_single_t<32, 1, 0>(s, p);
+    launch_pw_single_t<32, 1, 0, 1>(s, p);
+  } else if (K == 512 && N == 256) {
+    if (res_mode == 0) launch_pw_single_t<32, 1, 0, 2>(s, p);
+    else launch_pw_single_t<32, 1, 2, 2>(s, p);
   } else {
-    if (res_mode == 0) launch_pw_single_t<8, 4, 0>(s, p);
-    else if (res_mode == 1) launch_pw_single_t<8, 4, 1>(s, p);
-    else launch_pw_single_t<8, 4, 2>(s, p);
+    if (res_mode == 0) launch_pw_single_t<8, 4, 0, 1>(s, p);
+    else if (res_mode == 1) launch_pw_single_t<8, 4, 1, 1>(s, p);
+    else launch_pw_single_t<8, 4, 2, 1>(s, p);
   }
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -380,10 +380,11 @@ def test_pointwise_pair_fusion_is_bit_identical(engines):
 def test_pointwise_stream_kernel_is_bit_identical(engines):
     """pw_single.hpp (layer2's 1x1 convs and the P2 lateral as a persistent kernel with register-resident weights) against the
     generic contraction kernel: the pyramid must not change by a bit.  The kernel takes over from 64 Ki output pixels: 85 frames of
-    224x224 give layer2 66640 pixels (not a multiple of the 32-pixel tile), 22 frames of 224x256 reach only the lateral."""
+    224x224 give layer2 66640 pixels (not a multiple of the 32-pixel tile), 22 frames of 224x256 reach only the lateral, 340 frames
+    bring in layer3 (channel-split workgroups) with 66640 pixels."""
     e = engines['bf16']
     try:
-        for shape in ((85, 224, 224), (22, 224, 256), (96, 224, 224)):
+        for shape in ((85, 224, 224), (22, 224, 256), (96, 224, 224), (340, 224, 224)):
             img = torch.from_numpy(synth.make_clips(67, 1, *shape)).to('cuda:0')
             e.set_option('pointwise_stream', 0)
             ref = [p.clone() for p in e.backbone_fpn(img)]
