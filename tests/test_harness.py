@@ -183,3 +183,20 @@ def test_dataset_tool_end_to_end(tmp_path, monkeypatch, capsys):
     recs = json.load(open(str(path)))
     assert [r['video_id'] for r in recs] == [1, 2] and [len(r['fusion_gazes']) for r in recs] == [8, 4]
     assert set(recs[0]) >= {'video_id', 'category_id', 'fusion_gazes', 'face_bboxes', 'face_gazes', 'face_score', 'eyes_gazes', 'head_gazes'}
+
+
+def test_mae_command_lines_print_the_reference_lines(golden_dir, tmp_path):
+    """tools/calculate_mae_{gaze360,l2cs}.py keep the reference scripts' flags (--evalfile / --anno) and printed lines."""
+    import subprocess, sys
+    g = json.load(open(os.path.join(golden_dir, 'metric_kat.json')))
+    ev, an, an3 = tmp_path / 'eval.json', tmp_path / 'anno.json', tmp_path / 'anno3.json'
+    ev.write_text(json.dumps(g['eval']))
+    an.write_text(json.dumps(g['anno']))
+    an3.write_text(json.dumps(dict(annotations=[a for a in g['anno']['annotations'] for _ in range(3)])))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'calculate_mae_gaze360.py'), '--evalfile', str(ev), '--anno', str(an)],
+                         capture_output=True, text=True, check=True).stdout
+    assert out == g['gaze360_printed'].split('face_gazes')[0]
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'calculate_mae_l2cs.py'), '--evalfile', str(ev), '--anno', str(an3)],
+                         capture_output=True, text=True, check=True).stdout
+    assert out == g['l2cs_printed']
