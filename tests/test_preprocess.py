@@ -36,6 +36,12 @@ def test_own_config_names_the_reference_test_pipeline():
     kinds = [t['type'] for t in cfg.data.test.pipeline]
     assert kinds == [t['type'] for t in GAZE360]
     P.DevicePipeline(cfg.data.test.pipeline)
+    # L2CS setting: same model through `_base_`, test pipeline replaced (`_delete_`), no crop, long side 448
+    l2 = Config.fromfile(os.path.join(ROOT, 'configs', 'mcgaze', 'r50_clip7_l2cs.py'))
+    assert l2.model == cfg.model and '_delete_' not in l2.data.test
+    assert [dict(t) for t in l2.data.test.pipeline] == L2CS and l2.data.test.img_prefix == 'data/l2cs/test_rawframes/'
+    assert l2.data.workers_per_gpu == cfg.data.workers_per_gpu   # inherited key survives the merge
+    P.DevicePipeline(l2.data.test.pipeline)
 
 
 @pytest.mark.parametrize('case', KAT['random_cases'], ids=lambda c: f"seed{c['seed']}")
