@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob(f'{out}/{sub}/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
-            if 'igemm' in row['Kernel_Name'] or 'pw_pair' in row['Kernel_Name']:
+            if 'igemm' in row['Kernel_Name'] or 'pw_pair' in row['Kernel_Name'] or 'pw_single' in row['Kernel_Name']:
                 agg[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
 res = {}
 for k, d in agg.items():
@@ -26,6 +26,8 @@ for k, d in agg.items():
         name = f'igemm_dma_kernel<float,{",".join(m.groups())},x3>'
     if 'pw_pair' in k:
         name = 'pw_pair_kernel (conv3 + next conv1, layer1)'
+    if 'pw_single' in k:
+        name = 'pw_single_kernel (HBM-bound 1x1 convs, register-resident weights)'
     e = res.setdefault(name, {'fetch_total': 0.0, 'write_total': 0.0, 'launches_sampled': 0})
     e['fetch_total'] += sum(d['FETCH_SIZE']) * 1024 * 2   # KiB units; x2: gfx950 FETCH_SIZE counts 128-B requests as 64 B
     e['write_total'] += sum(d['WRITE_SIZE']) * 1024
