@@ -46,6 +46,7 @@ __device__ __forceinline__ u32x4 make_srd(const void* base) {
   return r;
 }
 #define MCG_OOB_OFFSET 0xFFFFFF00u
+#define MCG_MAX_DEVICES 64                // per-device launch state (CU count, raised LDS limit) of the persistent kernels
 #define MCG_DMA_MAX_BYTES 0x7FFFFF00ll  // operands must fit the 2 GiB descriptor window
 
 // One wave-wide 1 KiB HBM -> LDS piece: lane l's 16 bytes land at LDS (lds_base_uniform + IMM) + 16 * l.

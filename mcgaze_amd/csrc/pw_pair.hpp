@@ -228,13 +228,16 @@ static inline bool pw_pair_applicable(int K1, int K2, int stride2, int C, int C2
 template <int NSRC, int C2T>
 static inline void launch_pw_pair_t(hipStream_t s, const PwPairParams& p) {
   constexpr int kLds = (NSRC == 1 ? 2 * 64 * 512 + 64 * 128 : 64 * 512 + 2 * 2 * 64 * 128) + (256 + 128) * 4;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
+  // per device (a process may hold engines on several GPUs): CU count, and the kernel's dynamic-LDS limit raised once
+  static int cus_of[MCG_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
+  if (!cus_of[dev]) {
     hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     (void)hipFuncSetAttribute((const void*)pw_pair_kernel<NSRC, C2T>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
+  const int cus = cus_of[dev];
   const int ntiles = (p.M + 63) / 64;
   const int wgs = 2 * cus;                                     // two workgroups per CU (2 x 80 KiB of LDS fit exactly)
   hipLaunchKernelGGL((pw_pair_kernel<NSRC, C2T>), dim3(ntiles < wgs ? ntiles : wgs), dim3(256), kLds, s, p);

@@ -165,13 +165,16 @@ static inline void launch_pw_single_t(hipStream_t s, const PwSingleParams& p) {
   constexpr int NAB = (2 * AB + NYB * YB + BB <= 80 * 1024) ? 2 : 1;
   constexpr int kLds = NYB * YB + NAB * AB + BB;
   static_assert(kLds <= 80 * 1024, "two workgroups per CU");
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
+  // per device (a process may hold engines on several GPUs): CU count, and the kernel's dynamic-LDS limit raised once
+  static int cus_of[MCG_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
+  if (!cus_of[dev]) {
     hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     (void)hipFuncSetAttribute((const void*)pw_single_kernel<KS, TPW, RES, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
+  const int cus = cus_of[dev];
   const int ntiles = (p.M + 31) / 32, unit = 8 * NSPLIT;
   int wgs = 2 * cus / unit * unit;                              // two workgroups per CU, whole groups of NSPLIT slices x 8 XCDs
   const int need = (ntiles + 7) / 8 * unit;
