@@ -231,7 +231,8 @@ int mcg_clip_forward(mcg_engine* e, mcg_stream s, const float* img, int num_fram
  * (formatting.py:229-231).  frames_dev: DEVICE array of num_frames descriptors; every src points at a decoded uint8 frame in
  * device memory, 3 interleaved channels in cv2 order (BGR), rows src_pitch bytes apart.  The crop window must lie inside the
  * frame; (out_h, out_w) is the resized size, <= (pad_h, pad_w).  dst: [num_frames][3][pad_h][pad_w] f32 = the `img` tensor
- * mcg_clip_forward takes.  mean / stdinv: host arrays, channel order of the OUTPUT (RGB when to_rgb). */
+ * mcg_clip_forward takes.  mean / stdinv: host arrays, channel order of the OUTPUT (RGB when to_rgb).  to_rgb is a plain swap of
+ * channels 0 and 2 on the way out: a caller whose decoder already delivers RGB passes the frames as they are and to_rgb = 0. */
 typedef struct mcg_frame_desc {
   const void* src;
   int src_h, src_w, src_pitch;

@@ -147,26 +147,57 @@ def run_videos(engine, videos, clip_len=7, stride=4, batch_clips=64, scale_facto
     return _run_windows(engine, [v['id'] for v in videos], plans, get_window, batch_clips, person_threshold)
 
 
-def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_clips=64, person_threshold=0.5, rng=None):
+def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_clips=64, person_threshold=0.5, rng=None, workers=0, lookahead=None):
     """tools/test_gaze360_gaze.py:57-269 from the annotation file down: for every ``anno['videos']`` entry (``id``,
     ``file_names``) each window's frames are loaded and preprocessed ANEW through ``pipeline`` (a
     mcgaze_amd.pipeline.DevicePipeline built from cfg.data.test.pipeline) -- like the reference, which re-runs its test
     pipeline, random crop included, for every window (:88-100) -- then all windows go through the engine in large batches
     and are merged per video.  Frames of a window are drawn in file-name order (the reference sorts its threads' results by
-    file name, :96); ``rng`` seeds the crop draws (default: the global numpy RNG, as upstream)."""
+    file name, :96); ``rng`` seeds the crop draws (default: the global numpy RNG, as upstream).
+    Each file is decoded once while it stays cached (windows overlap by three frames); windows are preprocessed in groups (one
+    pinned copy and one launch per padded size).  ``workers`` > 0 adds host threads that decode ``lookahead`` windows ahead of the
+    consumer (the reference uses 7 loader threads per window, :88-95) -- measured slower than in-line decoding for small frames
+    (pipeline.FrameCache), hence 0 by default.  The records do not depend on either."""
     import numpy as np
+    import os
+    from .pipeline import FrameCache
     rng = np.random if rng is None else rng
     videos = anno['videos']
     plans = [plan_windows(len(v['file_names']), clip_len, stride) for v in videos]
+    order = [(vi, wi) for vi, plan in enumerate(plans) for wi in range(len(plan))]     # the order _run_windows visits windows in
+    pos = {vw: i for i, vw in enumerate(order)}
+    lookahead = 2 * batch_clips if lookahead is None else lookahead
+    group = max(1, min(batch_clips, 32))                                    # windows staged per preprocessing call
+    cache = FrameCache(workers, capacity=(lookahead + group + 2) * clip_len)
+    state = dict(ahead=0)
+
+    def names_of(vi, wi):
+        a, b, _ = plans[vi][wi]
+        return sorted(videos[vi]['file_names'][a:b])
+
+    staged = {}
 
     def get_window(vi, wi):
-        a, b, _ = plans[vi][wi]
-        names = sorted(videos[vi]['file_names'][a:b])
-        img, metas = pipeline(names, device=engine.device, rng=rng, img_prefix=root)
+        i = pos[(vi, wi)]
+        if i not in staged:
+            # stage the next `group` windows in one go (one pinned copy, one launch per padded size); planned in visiting order, so
+            # the crop draws fall exactly where they do one window at a time
+            todo = order[i:i + group]
+            if workers > 0:
+                while state['ahead'] < min(i + len(todo) + lookahead, len(order)):   # decoders stay `lookahead` windows ahead
+                    v2, w2 = order[state['ahead']]
+                    cache.prefetch(os.path.join(root, n) if root is not None else n for n in names_of(v2, w2))
+                    state['ahead'] += 1
+            res = pipeline.run_many([names_of(v2, w2) for v2, w2 in todo], device=engine.device, rng=rng, img_prefix=root, loader=cache)
+            staged.update({i + k: r for k, r in enumerate(res)})
+        img, metas = staged.pop(i)
         hw = [m['img_shape'][:2] for m in metas]
         return img, hw, np.stack([m['scale_factor'] for m in metas])
 
-    return _run_windows(engine, [v['id'] for v in videos], plans, get_window, batch_clips, person_threshold)
+    try:
+        return _run_windows(engine, [v['id'] for v in videos], plans, get_window, batch_clips, person_threshold)
+    finally:
+        cache.close()
 
 
 def dump_results(records, config_path, json_path, out_dir='results'):

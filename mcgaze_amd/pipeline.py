@@ -18,8 +18,11 @@ time too (transforms.py:1126-1130), and ``RandomFlip(flip_r
 (np.random.choice, transforms.py:463-497).  ``rng`` (default: the global ``np.random``) is drawn from in that order per frame,
 so a seeded single-threaded run reproduces the reference's windows; ``crop_u=<float>`` pins the draw instead.
 """
+import collections
+import concurrent.futures
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 import torch
@@ -54,14 +57,64 @@ class LoadImageFromFile:
             raise NotImplementedError('LoadImageFromFile: only uint8 colour BGR frames from disk feed the device pipeline')
 
     @staticmethod
-    def load(filename):
+    def load(filename, rgb=False):
+        """-> HxWx3 uint8, BGR like cv2.imread's (rgb=True: the decoder's RGB order as it is -- the pixel kernel swaps channels
+        either way, and the per-frame flip copy is saved)."""
         from PIL import Image
         with Image.open(filename) as im:
-            rgb = np.asarray(im.convert('RGB'))
-        return np.ascontiguousarray(rgb[..., ::-1])
+            arr = np.asarray(im.convert('RGB'))
+        return arr if rgb else np.ascontiguousarray(arr[..., ::-1])
 
     def plan(self, p, rng):
         pass
+
+
+class FrameCache:
+    """Decoded frames by path: each file is decoded once while it stays cached (LRU), optionally ahead of the consumer.
+
+    The reference harness decodes a frame again for every window it belongs to (windows overlap by three frames,
+    tools/test_gaze360_gaze.py:88-100).  Here a decode is shared by the windows that use the frame.  With ``workers`` > 0 a pool of
+    host threads decodes what ``prefetch`` names ahead of the consumer (the reference uses seven loader threads); measured on the
+    GPU box this LOSES to in-line decoding for small frames (a 360x360 JPEG decodes in 0.5 ms; the threads contend with the
+    consumer for the interpreter lock and the allocator), so the default is in-line.  Only the DECODE is shared: crop draws, geometry
+    and the pixel kernel still run per window, in the caller's order -- results do not depend on the cache or the thread count."""
+
+    def __init__(self, workers=0, capacity=512, loader=None):
+        self.rgb = loader is None                   # our own decode keeps the decoder's RGB order (DevicePipeline.run_many swaps in the kernel)
+        self.loader = loader or (lambda path: LoadImageFromFile.load(path, rgb=True))
+        self.capacity = max(int(capacity), 1)
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix='mcg-decode') if workers > 0 else None
+        self.items = collections.OrderedDict()      # path -> Future (pool) or array (in line), least recently used first
+        self.lock = threading.Lock()
+        self.decodes = 0
+
+    def _entry(self, path, wanted_now):
+        with self.lock:
+            e = self.items.get(path)
+            if e is not None:
+                self.items.move_to_end(path)
+                return e
+            if self.pool is None and not wanted_now:
+                return None                         # in-line mode: prefetch is a no-op, the decode happens when the frame is asked for
+            e = self.items[path] = self.pool.submit(self.loader, path) if self.pool is not None else self.loader(path)
+            self.decodes += 1
+            while len(self.items) > self.capacity:
+                self.items.popitem(last=False)
+            return e
+
+    def prefetch(self, paths):
+        if self.pool is not None:
+            for p in paths:
+                self._entry(p, False)
+
+    def __call__(self, path):
+        e = self._entry(path, True)
+        return e.result() if isinstance(e, concurrent.futures.Future) else e
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown(wait=False, cancel_futures=True)
+        self.items.clear()
 
 
 @PIPELINES.register_module()
@@ -257,50 +310,102 @@ class DevicePipeline:
             p.scale_factor = 1.0
         return p
 
-    def __call__(self, frames, device='cuda:0', rng=np.random, img_prefix=None, stream=None):
+    def __call__(self, frames, device='cuda:0', rng=np.random, img_prefix=None, stream=None, loader=None):
         """frames: list of HxWx3 uint8 BGR arrays (cv2 order) or file names.  Returns (img [N,3,Hp,Wp] f32 on `device`,
-        img_metas list of N dicts) -- one clip batch, padded to the largest padded frame like mmcv's collate."""
+        img_metas list of N dicts) -- one clip batch, padded to the largest padded frame like mmcv's collate.
+        loader: path -> HxWx3 uint8 array (default LoadImageFromFile.load; a FrameCache decodes ahead on host threads)."""
+        return self.run_many([frames], device, rng, img_prefix, stream, loader)[0]
+
+    def _staging(self, nbytes, dev):
+        """A pinned host buffer of at least nbytes, one of two that alternate: the copy out of the other may still be in flight.
+        (A fresh ``pin_memory()`` per call costs milliseconds once decode threads compete for the allocator.)"""
+        i = self._pin_i = (getattr(self, '_pin_i', 0) + 1) & 1
+        if not hasattr(self, '_pin'):
+            self._pin, self._pin_ev = [None, None], [None, None]
+        if self._pin_ev[i] is not None:
+            self._pin_ev[i].synchronize()
+        if self._pin[i] is None or self._pin[i].numel() < nbytes:
+            self._pin[i] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8).pin_memory()
+        return i, self._pin[i]
+
+    def run_many(self, windows, device='cuda:0', rng=np.random, img_prefix=None, stream=None, loader=None):
+        """Several clip batches (windows) through ONE staging copy and one launch per distinct padded size: windows = list of lists
+        of frames (arrays or file names) -> list of (img, img_metas), each exactly what ``__call__`` returns for that window -- frames
+        are planned window by window, frame by frame, so the RNG draws fall where they do one window at a time; padding is per
+        window (mmcv's collate pads a clip to ITS largest frame)."""
         lib = L.load()
         dev = torch.device(device)
         if dev.type != 'cuda':
             raise L.McgError('DevicePipeline runs its pixel work on the GPU (mcg_preprocess_frames); there is no CPU path')
-        arrays, plans = [], []
-        for f in frames:
-            if isinstance(f, str):
-                path = os.path.join(img_prefix, f) if img_prefix is not None else f
-                arr, names = LoadImageFromFile.load(path), (path, f)
-            else:
-                arr, names = np.ascontiguousarray(f), (None, None)
-            if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
-                raise TypeError(f'frames must be HxWx3 uint8 arrays, got {arr.dtype} {arr.shape}')
-            arrays.append(arr)
-            plans.append(self.plan(arr.shape, rng, *names))
+        rgb_source = all(isinstance(f, str) for w in windows for f in w)      # our own decode: keep PIL's RGB order, the kernel swaps
+        if loader is not None:
+            load = loader
+            rgb_source = rgb_source and bool(getattr(loader, 'rgb', False))
+        else:
+            load = (lambda path: LoadImageFromFile.load(path, rgb=True)) if rgb_source else LoadImageFromFile.load
+        arrays, plans, bounds = [], [], [0]
+        for frames in windows:
+            for f in frames:
+                if isinstance(f, str):
+                    path = os.path.join(img_prefix, f) if img_prefix is not None else f
+                    arr, names = load(path), (path, f)
+                    if not rgb_source and getattr(loader, 'rgb', False):
+                        arr = np.ascontiguousarray(arr[..., ::-1])           # mixed with caller-supplied BGR arrays: one order per call
+                else:
+                    arr, names = np.ascontiguousarray(f), (None, None)
+                if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
+                    raise TypeError(f'frames must be HxWx3 uint8 arrays, got {arr.dtype} {arr.shape}')
+                arrays.append(arr)
+                plans.append(self.plan(arr.shape, rng, *names))
+            bounds.append(len(arrays))
+        out = [None] * len(windows)
         n = len(arrays)
+        for wi in range(len(windows)):
+            if bounds[wi] == bounds[wi + 1]:
+                out[wi] = (torch.empty(0, 3, 0, 0, dtype=torch.float32, device=dev), [])
         if n == 0:
-            return torch.empty(0, 3, 0, 0, dtype=torch.float32, device=dev), []
-        pad_h, pad_w = max(p.pad_shape[0] for p in plans), max(p.pad_shape[1] for p in plans)
+            return out
         offs = np.cumsum([0] + [(a.size + 255) // 256 * 256 for a in arrays])
-        host = torch.empty(int(offs[-1]), dtype=torch.uint8).pin_memory()
-        for a, o in zip(arrays, offs):
-            host[int(o):int(o) + a.size] = torch.from_numpy(a.reshape(-1))
-        raw = host.to(dev, non_blocking=True)
-        desc = (L.FrameDesc * n)()
-        for i, (a, p) in enumerate(zip(arrays, plans)):
-            desc[i] = L.FrameDesc(raw.data_ptr() + int(offs[i]), a.shape[0], a.shape[1], a.shape[1] * 3, *p.crop, p.img_shape[0], p.img_shape[1])
-        desc_dev = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(dev)
+        with torch.cuda.device(dev):
+            slot, host = self._staging(int(offs[-1]), dev)
+            host_np = host.numpy()
+            for a, o in zip(arrays, offs):
+                host_np[int(o):int(o) + a.size] = a.reshape(-1)
+            raw = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)
+            raw.copy_(host[:int(offs[-1])], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._pin_ev[slot] = ev
         norm = plans[0].img_norm_cfg
         mean = (C.c_float * 3)(*[float(v) for v in norm['mean']])
         stdinv = (C.c_float * 3)(*[float(np.float32(1.0 / np.float64(v))) for v in norm['std']])
-        img = torch.empty(n, 3, pad_h, pad_w, dtype=torch.float32, device=dev)
+        swap = int(bool(norm['to_rgb']) != rgb_source)        # channel swap the kernel performs: wanted order differs from the source's
+        groups = {}                                           # padded size -> windows
+        for wi in range(len(windows)):
+            a, b = bounds[wi], bounds[wi + 1]
+            if b > a:
+                pad = (max(p.pad_shape[0] for p in plans[a:b]), max(p.pad_shape[1] for p in plans[a:b]))
+                groups.setdefault(pad, []).append(wi)
+        keep = [raw]
         s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
-        L.check(lib.mcg_preprocess_frames(C.c_void_p(s), C.c_void_p(desc_dev.data_ptr()), n, C.c_void_p(img.data_ptr()), pad_h, pad_w,
-                                          mean, stdinv, int(bool(norm['to_rgb']))), 'mcg_preprocess_frames')
-        self._scratch = dict(raw=raw, desc=desc_dev)     # keep the inputs alive until the stream has consumed them
-        metas = []
-        for p in plans:
-            m = self.collect.meta(p)
-            metas.append(m)
-        return img, metas
+        for (pad_h, pad_w), wis in groups.items():
+            idx = [k for wi in wis for k in range(bounds[wi], bounds[wi + 1])]
+            desc = (L.FrameDesc * len(idx))()
+            for i, k in enumerate(idx):
+                a, p = arrays[k], plans[k]
+                desc[i] = L.FrameDesc(raw.data_ptr() + int(offs[k]), a.shape[0], a.shape[1], a.shape[1] * 3, *p.crop, p.img_shape[0], p.img_shape[1])
+            desc_dev = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(dev)
+            img = torch.empty(len(idx), 3, pad_h, pad_w, dtype=torch.float32, device=dev)
+            L.check(lib.mcg_preprocess_frames(C.c_void_p(s), C.c_void_p(desc_dev.data_ptr()), len(idx), C.c_void_p(img.data_ptr()), pad_h, pad_w,
+                                              mean, stdinv, swap), 'mcg_preprocess_frames')
+            keep.append(desc_dev)
+            at = 0
+            for wi in wis:
+                cnt = bounds[wi + 1] - bounds[wi]
+                out[wi] = (img[at:at + cnt], [self.collect.meta(p) for p in plans[bounds[wi]:bounds[wi + 1]]])
+                at += cnt
+        self._scratch = dict(keep=keep)                       # keep the inputs alive until the stream has consumed them
+        return out
 
 
 def build_pipeline(transforms):

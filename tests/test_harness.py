@@ -117,7 +117,9 @@ def test_run_annotation_from_files_equals_window_by_window(tmp_path):
             os.makedirs(str(tmp_path / f'v{vid}'), exist_ok=True)
             Image.fromarray(rs.randint(0, 256, shape).astype(np.uint8)).save(str(tmp_path / names[-1]))
         anno['videos'].append(dict(id=vid + 10, file_names=names))
-    recs = harness.run_annotation(e, anno, str(tmp_path), pipe, batch_clips=3, rng=np.random.RandomState(21))
+    recs = harness.run_annotation(e, anno, str(tmp_path), pipe, batch_clips=3, rng=np.random.RandomState(21))   # in-line decode, cached
+    for workers, lookahead in ((8, None), (3, 1)):   # decode threads ahead of the GPU / a short look-ahead with evictions: the records may not depend on it
+        assert harness.run_annotation(e, anno, str(tmp_path), pipe, batch_clips=3, rng=np.random.RandomState(21), workers=workers, lookahead=lookahead) == recs
     rng = np.random.RandomState(21)
     for v, rec in zip(anno['videos'], recs):
         plan = harness.plan_windows(len(v['file_names']))
@@ -200,3 +202,35 @@ def test_mae_command_lines_print_the_reference_lines(golden_dir, tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'calculate_mae_l2cs.py'), '--evalfile', str(ev), '--anno', str(an3)],
                          capture_output=True, text=True, check=True).stdout
     assert out == g['l2cs_printed']
+
+
+def test_frame_cache_decodes_each_file_once_ahead_of_the_consumer():
+    """pipeline.FrameCache: decode on host threads, one decode per file while it stays cached, LRU eviction, loader errors surface
+    at the consumer."""
+    import threading, time
+    from mcgaze_amd.pipeline import FrameCache
+    seen, lock = [], threading.Lock()
+
+    def loader(path):
+        if path == 'bad':
+            raise OSError('cannot decode')
+        time.sleep(0.01)
+        with lock:
+            seen.append(path)
+        return np.full((2, 2, 3), int(path), dtype=np.uint8)
+
+    c = FrameCache(workers=0, capacity=2, loader=loader)                           # in line: prefetch is a no-op, decode on demand, LRU
+    c.prefetch(['1', '2'])
+    assert c.decodes == 0 and [int(c(p)[0, 0, 0]) for p in ('1', '2', '1', '3', '1', '2')] == [1, 2, 1, 3, 1, 2] and seen == ['1', '2', '3', '2']
+    c.close()
+    seen.clear()
+    c = FrameCache(workers=4, capacity=6, loader=loader)
+    c.prefetch(str(i) for i in range(6))
+    assert [int(c(str(i))[0, 0, 0]) for i in (0, 1, 2, 3, 4, 5, 2, 3)] == [0, 1, 2, 3, 4, 5, 2, 3]
+    assert sorted(seen) == [str(i) for i in range(6)] and c.decodes == 6          # overlapping windows: no second decode
+    c.prefetch(['6', '7'])                                                         # capacity 6: the least recently used (0, 1) go
+    assert int(c('7')[0, 0, 0]) == 7 and int(c('0')[0, 0, 0]) == 0 and c.decodes == 9
+    c.prefetch(['bad'])
+    with pytest.raises(OSError):
+        c('bad')
+    c.close()

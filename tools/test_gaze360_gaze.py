@@ -51,6 +51,7 @@ def parse_args(argv=None):
                     help="'bf16x3' (default): parity-grade fast engine; 'fp32': exact reference mode; 'bf16': throughput mode (not within the 1e-3 tolerance)")
     ap.add_argument('--batch-clips', type=int, default=64)
     ap.add_argument('--seed', type=int, default=None)
+    ap.add_argument('--workers', type=int, default=0, help='host threads decoding frames ahead of the GPU (0 = decode in line, the faster choice for small frames)')
     ap.add_argument('--anno', default=None, help='ground-truth annotation json: print the MAE')
     ap.add_argument('--setting', default=None, choices=['gaze360', 'l2cs'], help='metric variant (default: from the config name)')
     a = ap.parse_args(argv)
@@ -75,7 +76,7 @@ def main(argv=None):
     anno = json.load(open(a.json))
     idx = shard_videos(anno['videos'], world, rank)
     rng = np.random.RandomState(a.seed + rank) if a.seed is not None else None
-    recs = harness.run_annotation(model.engine(), dict(videos=[anno['videos'][i] for i in idx]), a.root, pipe, batch_clips=a.batch_clips, rng=rng)
+    recs = harness.run_annotation(model.engine(), dict(videos=[anno['videos'][i] for i in idx]), a.root, pipe, batch_clips=a.batch_clips, rng=rng, workers=a.workers)
     if world > 1:
         recs = gather_records(idx, recs, len(anno['videos']))
     if rank == 0:
