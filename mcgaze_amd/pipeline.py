@@ -299,6 +299,7 @@ class DevicePipeline:
             raise ValueError(f'unsupported test pipeline {kinds}: need ... Normalize ... DefaultFormatBundle, Collect')
         self.collect = self.transforms[-1]
         self._scratch = {}
+        self._pin, self._pin_ev, self._pin_i = [None, None], [None, None], 0   # pinned staging buffers (two, alternating) and their copy-done events
 
     def plan(self, shape, rng=np.random, filename=None, ori_filename=None):
         p = FramePlan(shape, filename, ori_filename)
@@ -319,9 +320,7 @@ class DevicePipeline:
     def _staging(self, nbytes, dev):
         """A pinned host buffer of at least nbytes, one of two that alternate: the copy out of the other may still be in flight.
         (A fresh ``pin_memory()`` per call costs milliseconds once decode threads compete for the allocator.)"""
-        i = self._pin_i = (getattr(self, '_pin_i', 0) + 1) & 1
-        if not hasattr(self, '_pin'):
-            self._pin, self._pin_ev = [None, None], [None, None]
+        i = self._pin_i = (self._pin_i + 1) & 1
         if self._pin_ev[i] is not None:
             self._pin_ev[i].synchronize()
         if self._pin[i] is None or self._pin[i].numel() < nbytes:
