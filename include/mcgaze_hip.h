@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 5
+#define MCG_ABI_VERSION 6
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
 /* MCG_BF16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
@@ -131,6 +131,7 @@ enum {
   MCG_SW_OUT_PROJ_WF, MCG_SW_CLS_FC_WF,
   MCG_SW_REG_FC_WF,  /* [3] x fragment-major */
   MCG_SW_IN_PROJ_WF, /* in_proj_weight [768][256] fragment-major (t < 24 column tiles) for the fused attention block (attn_block.hpp) */
+  MCG_SW_DYN_WF,     /* dynamic_layer.weight [32768][256] (rows permuted like the row-major entry) fragment-major, t < 1024 (pw_single.hpp) */
   MCG_SW_COUNT
 };
 enum {

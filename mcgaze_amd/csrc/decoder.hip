@@ -4,6 +4,7 @@
 #include "igemm.hpp"
 #include "chain.hpp"
 #include "attn_block.hpp"
+#include "pw_single.hpp"
 
 #include <string.h>
 
@@ -447,7 +448,18 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
     xin = xout[pass];
   }
   // --- DynamicConv (transformer.py:1116-1164)
-  MCG_TRY(launch_linear(s, dt, w.x2, 256, W[MCG_SW_DYN_W], f32w[MCG_SW_DYN_B], nullptr, 0, w.params, 32768, R, 256, 32768, 0, ctx));
+  if (bf && ctx.chain && ctx.tile < 0 && !ctx.staged && pw_dyn_applicable(R)) {
+    // few rows, 32768 columns: 256-column weight slices resident in registers, tokens streamed (pw_single.hpp); bit-identical to the generic kernel
+    PwSingleParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.a = w.x2; pp.wf = W[MCG_SW_DYN_WF]; pp.bias = f32w[MCG_SW_DYN_B]; pp.y = w.params; pp.M = R; pp.Ho = 1; pp.Wo = 1;
+    ProfRec* rec = prof_begin(ctx, s, 62, R, 32768, 256, 2.0 * R * 32768 * 256);
+    const int rc = launch_pw_dyn(s, pp);
+    prof_end(rec, s);
+    if (rc) { mcg_set_error("pw_single (dynamic_layer) launch failed"); return MCG_ERR_HIP; }
+  } else {
+    MCG_TRY(launch_linear(s, dt, w.x2, 256, W[MCG_SW_DYN_W], f32w[MCG_SW_DYN_B], nullptr, 0, w.params, 32768, R, 256, 32768, 0, ctx));
+  }
   if (bf) hipLaunchKernelGGL(dynconv_kernel<bf16_t>, dim3(R), dim3(256), 0, s, (const bf16_t*)roi_feat, (const bf16_t*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (bf16_t*)w.feat2);
   else hipLaunchKernelGGL(dynconv_kernel<float>, dim3(R), dim3(256), 0, s, (const float*)roi_feat, (const float*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (float*)w.feat2);
   MCG_CHECK_LAUNCH("dynconv");

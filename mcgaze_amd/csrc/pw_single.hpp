@@ -20,6 +20,7 @@ struct PwSingleParams {
   void* y;                  // [M][N]
   int M, relu, Ho, Wo, Hr, Wr;
   float rscale_h, rscale_w;
+  int many_slices;          // 1: far more channel slices than XCDs (dynamic_layer: 128): workgroup id = walker * NSPLIT + slice
 };
 
 // K = 16 KS; a workgroup owns N = 128 TPW output channels (TPW 32-channel tiles per wave, 4 waves) of the NSPLIT * N the layer has:
@@ -40,7 +41,8 @@ __global__ __launch_bounds__(256, 2) void pw_single_kernel(const PwSingleParams 
   const int tid = threadIdx.x, lane = tid & 63, px = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // blockIdx -> (walker, channel slice): ids 8 apart sit on the same XCD (round-robin dispatch over the 8 XCDs)
-  const int bid = blockIdx.x, nsp = (bid >> 3) % NSPLIT, walker = (bid / (8 * NSPLIT)) * 8 + (bid & 7), nwalkers = gridDim.x / NSPLIT;
+  const int bid = blockIdx.x, nwalkers = gridDim.x / NSPLIT;
+  const int nsp = p.many_slices ? bid % NSPLIT : (bid >> 3) % NSPLIT, walker = p.many_slices ? bid / NSPLIT : (bid / (8 * NSPLIT)) * 8 + (bid & 7);
   float4 breg[4];
   if constexpr (BIAS_REGS) {
 #pragma unroll
@@ -200,5 +202,29 @@ static inline int launch_pw_single(hipStream_t s, const PwSingleParams& p, int K
     else if (res_mode == 1) launch_pw_single_t<8, 4, 1, 1>(s, p);
     else launch_pw_single_t<8, 4, 2, 1>(s, p);
   }
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// DynamicConv's `dynamic_layer` (transformer.py:1131-1134): y[M][32768] = x[M][256] . W^T + b with FEW rows (1344 tokens at 64 clips) and
+// 88 MB of output.  The generic kernel spends it in prologues and epilogues (4 K-tiles per 256x128 output tile: 55 us, 1.6 TB/s of
+// writes).  Here: 128 slices of 256 columns, each slice's weights resident in the registers of a few workgroups ("walkers") that
+// split the token tiles between them; the tokens (688 KB) stream out of L2.  Same arithmetic as every pw_single launch: bit-identical.
+static inline bool pw_dyn_applicable(int M) { return M >= 256 && (long long)M * 512 < MCG_DMA_MAX_BYTES; }
+static inline int launch_pw_dyn(hipStream_t s, PwSingleParams p) {
+  constexpr int KS = 16, TPW = 2, NSPLIT = 128, kLds = 32 * 512 + 2 * 32 * 512 + 256 * 4;   // y tile + two A tiles + biases
+  static int cus_of[MCG_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
+  if (!cus_of[dev]) {
+    hipDeviceProp_t prop;
+    (void)hipFuncSetAttribute((const void*)pw_single_kernel<KS, TPW, 0, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  const int ntiles = (p.M + 31) / 32;
+  int walkers = 2 * cus_of[dev] / NSPLIT;                       // two workgroups per CU (4 walkers per slice on 256 CUs; 2, 3, 6, 8 measured slower)
+  if (walkers < 1) walkers = 1;
+  if (walkers > ntiles) walkers = ntiles;
+  p.many_slices = 1;
+  hipLaunchKernelGGL((pw_single_kernel<KS, TPW, 0, NSPLIT>), dim3(walkers * NSPLIT), dim3(256), kLds, s, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -24,7 +24,6 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiLevels lv, int C, con
   __shared__ int s_lo[2][NS], s_hi[2][NS];
   __shared__ float s_l[2][NS], s_h[2][NS];
   __shared__ int s_valid[2][NS];
-  __shared__ int s_level;
   const int box = blockIdx.x, tid = threadIdx.x;
   const float x1 = boxes[box * 4 + 0], y1 = boxes[box * 4 + 1], x2 = boxes[box * 4 + 2], y2 = boxes[box * 4 + 3];
   // map_roi_levels (single_level_roi_extractor.py:51-54)
@@ -52,7 +51,6 @@ __global__ __launch_bounds__(256) void roi_align_kernel(RoiLevels lv, int C, con
     s_lo[axis][i] = lo; s_hi[axis][i] = hi; s_l[axis][i] = l; s_h[axis][i] = 1.f - l; s_valid[axis][i] = valid && (c == c);
   }
   if (tid == 0) {
-    s_level = level;
     if (levels_out) levels_out[box] = level;
   }
   __syncthreads();

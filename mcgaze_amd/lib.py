@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('MCGAZE_LIB') or os.path.join(_HERE, 'libmcgaze_hip.so
 
 MCG_OK = 0
 MCG_F32, MCG_BF16, MCG_BF16X3 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 RES_NONE, RES_ADD, RES_UPSAMPLE_ADD = 0, 1, 2
 FLAG_STAGED_GEMM, FLAG_NO_SPECIALISED = 1, 2
 
@@ -20,7 +20,7 @@ STAGE_KEYS = [
     'IN_PROJ_W', 'IN_PROJ_B', 'OUT_PROJ_W', 'OUT_PROJ_B', 'ATTN_LN_G', 'ATTN_LN_B', 'DYN_W', 'DYN_B',
     'NORM_IN_G', 'NORM_IN_B', 'NORM_OUT_G', 'NORM_OUT_B', 'FC_W', 'FC_B', 'FC_LN_G', 'FC_LN_B', 'IIC_LN_G', 'IIC_LN_B',
     'FFN1_W', 'FFN1_B', 'FFN2_W', 'FFN2_B', 'FFN_LN_G', 'FFN_LN_B', 'CLS_FC_W', 'CLS_LN_G', 'CLS_LN_B',
-    'REG_FC_W', 'REG_LN_G', 'REG_LN_B', 'HEAD_CLS_W', 'HEAD_CLS_B', 'HEAD_REG_W', 'HEAD_REG_B', 'OUT_PROJ_WF', 'CLS_FC_WF', 'REG_FC_WF', 'IN_PROJ_WF']
+    'REG_FC_W', 'REG_LN_G', 'REG_LN_B', 'HEAD_CLS_W', 'HEAD_CLS_B', 'HEAD_REG_W', 'HEAD_REG_B', 'OUT_PROJ_WF', 'CLS_FC_WF', 'REG_FC_WF', 'IN_PROJ_WF', 'DYN_WF']
 GAZE_KEYS = ['FC_W', 'LN_G', 'LN_B', 'OUT_W', 'OUT_B', 'FUSE_W', 'FUSE_B']
 SW_COUNT, GW_COUNT = len(STAGE_KEYS), len(GAZE_KEYS)
 

@@ -157,7 +157,7 @@ class PackedWeights:
                 HEAD_CLS_B=vec(torch.cat([sd[p + f'.{c}_fc_cls.bias'] for c in CLUES])),
                 HEAD_REG_W=vec(torch.stack([sd[p + f'.{c}_fc_reg.weight'] for c in CLUES])),
                 HEAD_REG_B=vec(torch.stack([sd[p + f'.{c}_fc_reg.bias'] for c in CLUES])))
-            for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W', 'IN_PROJ_W'):   # fragment-major copies for the fused chain / attention-block kernels (bf16 engine only)
+            for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W', 'IN_PROJ_W', 'DYN_W'):   # fragment-major copies for the fused chain / attention-block kernels (bf16 engine only)
                 st[k + 'F'] = frag_major(st[k]) if dtype == torch.bfloat16 else st[k]
             assert st['HEAD_CLS_W'].shape == (3, 256), 'use_sigmoid=True heads expected (gaze_stqi_head.py:72-75)'
             self.stages.append(st)

@@ -121,7 +121,7 @@ def test_library_exports_every_declared_symbol():
     # the binding's weight-table keys are the header's enums, in order
     sw = re.findall(r'MCG_SW_([A-Z0-9_]+)', hdr[hdr.index('MCG_SW_IN_PROJ_W = 0'):hdr.index('MCG_SW_COUNT')])
     gw = re.findall(r'MCG_GW_([A-Z0-9_]+)', hdr[hdr.index('MCG_GW_FC_W = 0'):hdr.index('MCG_GW_COUNT')])
-    assert sw == L.STAGE_KEYS and gw == L.GAZE_KEYS and L.SW_COUNT == 38 and L.GW_COUNT == 7
+    assert sw == L.STAGE_KEYS and gw == L.GAZE_KEYS and L.SW_COUNT == 39 and L.GW_COUNT == 7
 
 
 def test_dyn_permutation_matches_reference_view():

@@ -447,12 +447,13 @@ def test_decoder_stage(eng, sd, kind, B, T):
             assert v < STAGE_TOL[kind][k], (k, v)
 
 
-@pytest.mark.parametrize('B,T', [(1, 7), (5, 3), (11, 1), (2, 10), (1, 11), (64, 7)])
+@pytest.mark.parametrize('B,T', [(1, 7), (5, 3), (11, 1), (2, 10), (1, 11), (13, 7), (64, 7)])
 def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T):
     """attn_block.hpp (both attention passes of a stage as one launch, one clip per workgroup, for 3 T <= 32; T = 11 takes the
     per-pass chain) and chain.hpp (towers and attention out-projection + LayerNorm as single launches) keep the K order, the bf16 rounding points
     and the LayerNorm reduction order of the launch sequence it replaces -- incl. row counts that are not a multiple of its 32-row
-    block."""
+    block.  From 256 tokens on, `dynamic_layer` runs in skinny_linear.hpp (tokens resident, weight rows streamed): 13 x 7 frames give
+    273 tokens = two full token groups and one of 17."""
     from mcgaze_amd.packing import PackedWeights
     pw = PackedWeights(sd, dtype=torch.bfloat16)
     N = B * T
