@@ -187,6 +187,68 @@ def test_dataset_tool_end_to_end(tmp_path, monkeypatch, capsys):
     assert set(recs[0]) >= {'video_id', 'category_id', 'fusion_gazes', 'face_bboxes', 'face_gazes', 'face_score', 'eyes_gazes', 'head_gazes'}
 
 
+@pytest.mark.gpu
+def test_dataset_run_matches_the_cpu_oracle_end_to_end(tmp_path):
+    """BASELINE.json configs[4] in miniature: frames on disk -> decode -> preprocessing (seeded random crop per window) -> windows ->
+    default engine (bf16x3) -> overlap merge -> MAE, against the same chain on the CPU: oracle preprocessing + oracle forward per
+    window (the reference's arithmetic, pinned by the goldens) + the same merge.  Gaze vectors within north_star's 1e-3 rad, the
+    three MAE figures within 0.02 degrees (they are printed with two decimals)."""
+    from PIL import Image
+    from mcgaze_amd import Config, metric
+    from mcgaze_amd.engine import HipEngine
+    from mcgaze_amd.pipeline import DevicePipeline
+    from oracle import mcgaze_oracle as orc
+    from oracle import preprocess_oracle as po
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pipe = DevicePipeline(Config.fromfile(os.path.join(root, 'configs', 'mcgaze', 'r50_clip7_gaze360.py')).data.test.pipeline)
+    sd = synth.make_state_dict(0)
+    rs = np.random.RandomState(12)
+    anno, frames = dict(videos=[], annotations=[]), {}
+    for vid, (L, shape) in enumerate([(10, (260, 250, 3)), (5, (300, 280, 3))]):
+        names = []
+        os.makedirs(str(tmp_path / f'v{vid}'))
+        base = rs.randint(0, 256, (shape[0] // 6 + 1, shape[1] // 6 + 1, 3)).astype(np.uint8)
+        for i in range(L):   # smooth, frame-dependent content
+            img = np.asarray(Image.fromarray(np.roll(base, i, axis=1)).resize((shape[1], shape[0]), Image.BILINEAR))
+            names.append(f'v{vid}/{i:06d}.png')
+            Image.fromarray(img).save(str(tmp_path / names[-1]))
+            frames[names[-1]] = np.ascontiguousarray(img[..., ::-1])        # what cv2.imread would hand the reference: BGR
+        g = rs.randn(L, 3)
+        anno['videos'].append(dict(id=vid, file_names=names))
+        anno['annotations'].append(dict(gaze=(g / np.linalg.norm(g, axis=1, keepdims=True)).tolist()))
+    eng = HipEngine(sd, precision='bf16x3')
+    recs = harness.run_annotation(eng, anno, str(tmp_path), pipe, rng=np.random.RandomState(5))
+    # ---- the CPU chain
+    rng = np.random.RandomState(5)
+    want = []
+    for v in anno['videos']:
+        plan = harness.plan_windows(len(v['file_names']))
+        outs = []
+        for a, b, _ in plan:
+            chw, metas = [], []
+            for n in sorted(v['file_names'][a:b]):
+                u = rng.rand(1)[0]          # CenterCrop's draw, then RandomFlip's (transforms.py:1126-1130, 463-497)
+                rng.random_sample()
+                c, m = po.test_pipeline(frames[n], u=u)
+                chw.append(c)
+                metas.append(m)
+            det, gaze = orc.forward(sd, po.collate_clip(chw), metas, b - a, rescale=True)
+            others = torch.stack([gaze['face_gaze_score'], gaze['eyes_gaze_score'], gaze['head_gaze_score']], dim=1)
+            outs.append((det, gaze['gaze_score'], others))
+        want.append(harness.video_record(v['id'], *harness.merge_video(plan, outs)))
+    for rec, ref in zip(recs, want):
+        got, exp = torch.tensor(rec['fusion_gazes']), torch.tensor(ref['fusion_gazes'])
+        assert got.shape == exp.shape
+        assert float((orc.yaw_pitch(got) - orc.yaw_pitch(exp)).abs().max()) < 1e-3
+        for c in ('face', 'eyes', 'head'):
+            assert float((torch.tensor(rec[f'{c}_gazes']) - torch.tensor(ref[f'{c}_gazes'])).abs().max()) < 1e-3
+            assert np.allclose(np.array(rec[f'{c}_score']), np.array(ref[f'{c}_score']), atol=1e-3)
+    a = metric.gaze_error(recs, anno, verbose=False)
+    b = metric.gaze_error(want, anno, verbose=False)
+    for k in a:
+        assert abs(a[k] - b[k]) < 0.02 or (a[k] != a[k] and b[k] != b[k]), (k, a[k], b[k])
+
+
 def test_mae_command_lines_print_the_reference_lines(golden_dir, tmp_path):
     """tools/calculate_mae_{gaze360,l2cs}.py keep the reference scripts' flags (--evalfile / --anno) and printed lines."""
     import subprocess, sys
