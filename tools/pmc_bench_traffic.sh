@@ -27,7 +27,7 @@ for k, d in agg.items():
     if 'pw_pair' in k:
         name = 'pw_pair_kernel (conv3 + next conv1, layer1)'
     if 'pw_single' in k:
-        name = 'pw_single_kernel (HBM-bound 1x1 convs, register-resident weights)'
+        name = 'pw_single_kernel<16,2,0,128> (dynamic_layer)' if re.search(r'pw_single_kernel<16, 2, 0, 128>', k) else 'pw_single_kernel (HBM-bound 1x1 convs, register-resident weights)'
     e = res.setdefault(name, {'fetch_total': 0.0, 'write_total': 0.0, 'launches_sampled': 0})
     e['fetch_total'] += sum(d['FETCH_SIZE']) * 1024 * 2   # KiB units; x2: gfx950 FETCH_SIZE counts 128-B requests as 64 B
     e['write_total'] += sum(d['WRITE_SIZE']) * 1024
