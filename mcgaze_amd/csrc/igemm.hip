@@ -337,6 +337,10 @@ int stem_forward_ctx(hipStream_t s, mcg_dtype dt, const float* img, const void* 
     if (launch_stem_fused(s, img, w_stem, bias, y, N, H, W)) { mcg_set_error("stem_fused launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
   }
+  if (dt == MCG_BF16X3 && ctx.stem_fused) {  // the bf16x3 form of the same kernel; bit-identical to the three launches below
+    if (launch_stem_fused_x3(s, img, w_stem, bias, y, N, H, W)) { mcg_set_error("stem_fused (bf16x3) launch failed"); return MCG_ERR_HIP; }
+    return MCG_OK;
+  }
   const size_t es = dt == MCG_BF16 ? 2 : 4;
   const int Hp = H + 6, Wp = W + 8, Hc = H / 2, Wc = W / 2;
   char* packed = (char*)ws;

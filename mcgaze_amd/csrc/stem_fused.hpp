@@ -167,3 +167,152 @@ static inline int launch_stem_fused(hipStream_t s, const float* img, const void*
                      tiles_y * tiles_x, (int)total);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same for the bf16x3 engine (f32 activations, split-packed weights, three MFMAs per product): NCHW f32 frame -> conv 7x7/s2
+// + BN -> ReLU -> max-pool -> NHWC f32 in one kernel.  The three-kernel path costs that engine 1.38 ms per 448 frames (pack 0.11,
+// contraction 0.87, pool 0.39: the f32 conv map is 1.44 GB written and read back).  Differences from the bf16 kernel above:
+//   * the input window is split ONCE when it is parked in LDS -- hi = RNE_bf16(x), lo = RNE_bf16(x - hi) (split_f32x8's
+//     arithmetic) into two planes of [rows][40][4 ch] -- instead of once per fragment read;
+//   * a lane keeps the high AND low 16-byte chunks of its weight row for all 14 K-steps (112 VGPRs, from the split-packed matrix
+//     of packing.py::split_pack); each K-step issues lo.hi, hi.lo, hi.hi in the contraction kernel's order: bit-identical to it;
+//   * the conv tile is f32 ([pixel][64] x 4 bytes), so a workgroup owns 8 x 4 pooled pixels (17 x 9 conv pixels = 5 row blocks,
+//     40 KiB) to keep two workgroups per CU; the pool is a float4 max against 0.
+namespace stemx {
+constexpr int PTX = 8, PTY = 4;                   // pooled tile
+constexpr int CTX = 2 * PTX + 1, CTY = 2 * PTY + 1;   // conv tile 17 x 9
+constexpr int ITX = 2 * (CTX - 1) + 7, ITY = 2 * (CTY - 1) + 7;   // input tile 39 x 23
+constexpr int ITW = 40;
+constexpr int NPIX = CTX * CTY;                   // 153 conv pixels
+constexpr int MB = (NPIX + 31) / 32;              // 5 row blocks
+constexpr int KS = 14;
+constexpr int IN_BYTES = ITY * ITW * 8;           // one plane (hi or lo)
+constexpr int CONV_BYTES = MB * 32 * 256;
+}  // namespace stemx
+
+__global__ __launch_bounds__(256, 2) void stem_fused_x3_kernel(const float* __restrict__ img, const char* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ y, int H, int W, int Hc, int Wc, int Ho, int Wo, int tiles_x,
+                                                               int tiles, int total) {
+  using namespace stemx;
+  __shared__ __attribute__((aligned(16))) char s_hi[IN_BYTES];
+  __shared__ __attribute__((aligned(16))) char s_lo[IN_BYTES];
+  __shared__ __attribute__((aligned(16))) char s_conv[CONV_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t plane = (size_t)H * W;
+  // waves 0-1 own channels 0..31, waves 2-3 channels 32..63; of the 5 row blocks the even wave of a pair runs 0..2, the odd one 3..4
+  const int nb = wave >> 1, mb0 = (wave & 1) ? 3 : 0, mb1 = (wave & 1) ? MB : 3;
+  const int row = lane & 31, half = lane >> 5;
+  bf16x8 bh[KS], bl[KS];
+  {
+    const char* wl = w + (size_t)(nb * 32 + row) * (KS * 16 * 4) + half * 32;   // split-packed row: per 8 K elements 16 B of hi, 16 B of lo
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bh[ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + ks * 64));
+      bl[ks] = __builtin_bit_cast(bf16x8, *(const uint4*)(wl + ks * 64 + 16));
+    }
+  }
+  const float b = bias[nb * 32 + row];
+
+  constexpr int TRIPS = (ITY * ITW + 255) / 256;
+  float v[TRIPS][3];
+  auto origin = [&](int t, int& n, int& py0, int& px0) {
+    n = t / tiles;
+    const int r = t - n * tiles, ty = r / tiles_x;
+    py0 = ty * PTY;
+    px0 = (r - ty * tiles_x) * PTX;
+  };
+  auto fetch = [&](int t) {
+    int n, py0, px0;
+    origin(t, n, py0, px0);
+    const int iy0 = 4 * py0 - 5, ix0 = 4 * px0 - 5;
+    const float* f0 = img + (size_t)n * 3 * plane;
+#pragma unroll
+    for (int j = 0; j < TRIPS; ++j) {
+      const int idx = tid + j * 256;
+      const int r = idx / ITW, c = idx - r * ITW;
+      const int gy = iy0 + r, gx = ix0 + c;
+      v[j][0] = v[j][1] = v[j][2] = 0.f;
+      if (idx < ITY * ITW && c < ITX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+        const float* p = f0 + (size_t)gy * W + gx;
+        v[j][0] = p[0]; v[j][1] = p[plane]; v[j][2] = p[2 * plane];
+      }
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int j = 0; j < TRIPS; ++j) {
+      const int idx = tid + j * 256;
+      if (idx < ITY * ITW) {
+        const uint32_t h01 = pack2bf(v[j][0], v[j][1]), h2 = pack2bf(v[j][2], 0.f);
+        const uint32_t l01 = pack2bf(v[j][0] - __uint_as_float(h01 << 16), v[j][1] - __uint_as_float(h01 & 0xffff0000u));
+        const uint32_t l2 = pack2bf(v[j][2] - __uint_as_float(h2 << 16), 0.f);
+        *(uint2*)(s_hi + idx * 8) = make_uint2(h01, h2);
+        *(uint2*)(s_lo + idx * 8) = make_uint2(l01, l2);
+      }
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < total) fetch(t);
+  for (; t < total; t += gridDim.x) {
+    park();
+    __syncthreads();
+    const int tn = t + gridDim.x;
+    if (tn < total) fetch(tn);
+    int n, py0, px0;
+    origin(t, n, py0, px0);
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;
+#pragma unroll 1
+    for (int mb = mb0; mb < mb1; ++mb) {
+      const int m = min(mb * 32 + row, NPIX - 1);
+      const int cy = m / CTX, cx = m - cy * CTX;
+      const int a0 = ((2 * cy) * ITW + 2 * cx + 2 * half) * 8;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = a0 + ((ks >> 1) * ITW + (ks & 1) * 4) * 8;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(s_hi + off));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(s_lo + off));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc, 0, 0, 0);
+      }
+      const int mbase = mb * 32 + 4 * half;
+      float* crow = (float*)(s_conv + mbase * 256) + nb * 32 + row;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) crow[((r & 3) + 8 * (r >> 2)) * 64] = acc[r] + b;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < PTX * PTY * 16; idx += 256) {
+      const int cc = idx & 15, pp = idx >> 4;
+      const int py = pp / PTX, px = pp - py * PTX;
+      if (py0 + py >= Ho || px0 + px >= Wo) continue;
+      float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);   // max with 0 = ReLU, then the pool's max
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        if ((unsigned)(cy0 + 2 * py + dy) >= (unsigned)Hc) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          if ((unsigned)(cx0 + 2 * px + dx) >= (unsigned)Wc) continue;
+          const float4 c = *(const float4*)(s_conv + ((2 * py + dy) * CTX + 2 * px + dx) * 256 + cc * 16);
+          mx.x = fmaxf(mx.x, c.x); mx.y = fmaxf(mx.y, c.y); mx.z = fmaxf(mx.z, c.z); mx.w = fmaxf(mx.w, c.w);
+        }
+      }
+      *(float4*)(y + (((size_t)n * Ho + py0 + py) * Wo + px0 + px) * 64 + cc * 4) = mx;
+    }
+  }
+}
+
+static inline int launch_stem_fused_x3(hipStream_t s, const float* img, const void* w_stem, const float* bias, void* y, int N, int H, int W) {
+  const int Hc = H / 2, Wc = W / 2, Ho = (Hc + 2 - 3) / 2 + 1, Wo = (Wc + 2 - 3) / 2 + 1;
+  const int tiles_y = (Ho + stemx::PTY - 1) / stemx::PTY, tiles_x = (Wo + stemx::PTX - 1) / stemx::PTX;
+  const long long total = (long long)tiles_y * tiles_x * N;
+  if (total > 0x7fffffffLL) return 1;
+  const int grid = (int)(total < 256 * 2 ? total : 256 * 2);  // persistent: 2 workgroups per CU (14.4 + 40 KiB of LDS each)
+  hipLaunchKernelGGL(stem_fused_x3_kernel, dim3(grid), dim3(256), 0, s, img, (const char*)w_stem, bias, (float*)y, H, W, Hc, Wc, Ho, Wo, tiles_x,
+                     tiles_y * tiles_x, (int)total);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}

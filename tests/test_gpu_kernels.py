@@ -307,6 +307,12 @@ def test_fused_stem_is_bit_identical_to_the_three_kernel_path(eng, sd, shape):
     torch.cuda.synchronize()
     assert a.shape == b.shape == (n, h // 4, w // 4, 64)
     assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    # the bf16x3 form (f32 activations, split-packed weights, 8 x 4 pooled tiles: 36x52 -> 9x13 is ragged in both directions)
+    px = PackedWeights(sd, dtype=torch.float32, split=True)
+    a = eng.stem(img, px.stem['w'], px.stem['bias'], torch.float32, flags=L.FLAG_NO_SPECIALISED, split=True).clone()
+    b = eng.stem(img, px.stem['w'], px.stem['bias'], torch.float32, split=True)
+    torch.cuda.synchronize()
+    assert a.shape == b.shape == (n, h // 4, w // 4, 64) and torch.equal(a, b)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
