@@ -156,3 +156,22 @@ def fake_clip_outputs(video_id, frames, call_index):
     g = rs.standard_normal((T, 4, 3)).astype(np.float32)
     g /= np.linalg.norm(g, axis=-1, keepdims=True)
     return torch.from_numpy(det), torch.from_numpy(g[:, 0]), torch.from_numpy(g[:, 1:])
+
+
+def fuzz_case(seed, index):
+    """One addressable random input of tools/parity_fuzz.py / the parity tests: weight seed, batch, clip length, padded frame size
+    (multiples of 32), per-frame img_shape inside it (40 % of the cases fill the frame), frames zero outside img_shape like the
+    pipeline's padding.  -> dict(wseed, B, T, H, W, img_shape, img [N,3,H,W] f32, metas)."""
+    rs = np.random.RandomState(1000003 * seed + index)
+    wseed = int(rs.randint(0, 3))
+    T = int(rs.choice([1, 2, 3, 5, 7, 7, 7, 9, 12]))
+    B = int(rs.randint(1, 4))
+    H, W = 32 * int(rs.randint(2, 11)), 32 * int(rs.randint(2, 11))
+    full = rs.rand() < 0.4
+    ih, iw = (H, W) if full else (int(rs.randint(H - 31, H + 1)), int(rs.randint(W - 31, W + 1)))
+    img = make_clips(7000 + 13 * seed + index, B, T, H, W)
+    if not full:
+        img[:, :, ih:, :] = 0
+        img[:, :, :, iw:] = 0
+    return dict(wseed=wseed, B=B, T=T, H=H, W=W, img_shape=(ih, iw), full=full, img=img,
+                metas=make_img_metas(B * T, (ih, iw, 3), pad_shape=(H, W, 3)))
