@@ -1,6 +1,6 @@
 """GPU tool: parity fuzz of the engines against the CPU oracle on random shapes -- clip length, batch, frame size (multiples of 32),
 per-frame img_shape inside the padded frame, weight seed -- to look for inputs where the parity-grade engines leave north_star's
-1e-3 rad on (yaw, pitch).  usage: python tools/parity_fuzz.py [cases=24] [seed=0] [precisions=bf16x3,fp32]"""
+1e-3 rad on (yaw, pitch).  usage: python tools/parity_fuzz.py [cases=24] [seed=0] [precisions=bf16x3,fp32] [diagnose=1]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,6 +14,7 @@ diag = []
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 precs = (sys.argv[3] if len(sys.argv) > 3 else 'bf16x3,fp32').split(',')
+diagnose = (sys.argv[4] if len(sys.argv) > 4 else '1') != '0'
 torch.set_num_threads(16)
 engines, sds = {}, {}
 worst = {p: 0.0 for p in precs}
@@ -41,7 +42,11 @@ for c in range(cases):
         worst[p] = max(worst[p], d)
         ang = float((2 * torch.asin(((out['gaze'][0].cpu().double() - ref['gaze_score'].double()).norm(dim=-1) / 2).clamp(max=1))).max())
         devs.append(f'{d:.2e} / {ang:.2e}')
-        if d > 1e-3:
+        if not np.isfinite(d):
+            counts[p]['NOT FINITE'] += 1
+        elif d > 1e-3 and not diagnose:
+            counts[p]['beyond 1e-3'] += 1
+        elif d > 1e-3:
             rep = PT.stage_report(engines[key], p, sds[wseed], img, metas, T, stages)
             note, disc = f'{p}: ' + PT.describe(rep), rep['discontinuity']
             err = orc.yaw_pitch(out['gaze'][0].cpu()) - want
