@@ -458,8 +458,8 @@ def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T):
     """attn_block.hpp (both attention passes of a stage as one launch, one clip per workgroup, for 3 T <= 32; T = 11 takes the
     per-pass chain) and chain.hpp (towers and attention out-projection + LayerNorm as single launches) keep the K order, the bf16 rounding points
     and the LayerNorm reduction order of the launch sequence it replaces -- incl. row counts that are not a multiple of its 32-row
-    block.  From 256 tokens on, `dynamic_layer` runs in skinny_linear.hpp (tokens resident, weight rows streamed): 13 x 7 frames give
-    273 tokens = two full token groups and one of 17."""
+    block.  From 256 tokens on, `dynamic_layer` runs through pw_single.hpp (128 column slices with register-resident weights, tokens streamed in
+    32-row tiles): 13 x 7 frames give 273 tokens = eight full tiles and one of 17 rows."""
     from mcgaze_amd.packing import PackedWeights
     pw = PackedWeights(sd, dtype=torch.bfloat16)
     N = B * T
