@@ -1,7 +1,9 @@
-// HBM-bound 1x1 convolutions of the bf16 trunk (layer2's conv1 512 -> 128 and conv3 128 -> 512 + residual, the FPN lateral 256 -> 256
-// + nearest-upsampled top-down term) as a persistent streaming kernel -- pw_pair.hpp's structure with one contraction:
+// HBM-bound 1x1 convolutions of the bf16 engine -- layer2's conv1 512 -> 128 and conv3 128 -> 512 + residual, layer3's conv3
+// 256 -> 1024 + residual and first conv1 512 -> 256, the FPN laterals P2 / P3 with their nearest-upsampled top-down term, and the
+// decoder's `dynamic_layer` (256 -> 32768 on 1344 tokens) -- as a persistent streaming kernel: pw_pair.hpp's structure with one
+// contraction,
 //
-//     y = [relu]( A . W^T + b (+ res | + up(res)) )        A [M][K], W [N][K], N * K * 2 B <= 128 KB
+//     y = [relu]( A . W^T + b (+ res | + up(res)) )        A [M][K], W [N][K]; per workgroup a slice of W of N_wg * K * 2 B <= 128 KB
 //
 // The generic contraction kernel runs these at 3.2-4.6 TB/s (a fresh prologue / epilogue per 256-row tile, K of 2-8 K-tiles); here a
 // workgroup keeps the whole weight matrix in REGISTERS (128 VGPRs per wave), walks 32-pixel tiles with a grid-stride loop, and the
