@@ -201,7 +201,8 @@ void mcg_engine_destroy(mcg_engine* e);
  *   tile              forces a contraction tile id (0 = heuristic), see mcg_conv_desc.tile
  *   staged_gemm, conv3x3_c64, stem_fused, decoder_chain   0/1 kernel-variant switches (defaults 0, 1, 1, 1)
  *   pointwise_pair    0/1 conv3 (+ residual) of a block and conv1 of the next as one kernel in layer1 (bf16; default 1)
- *   pointwise_stream  0/1 HBM-bound 1x1 convs (layer2, P2 lateral) by the persistent register-resident-weight kernel (bf16; default 1) */
+ *   pointwise_stream  0/1 HBM-bound 1x1 convs (layer2, layer3 conv3, P2 / P3 laterals) by the persistent register-resident-weight
+ *                     kernel pw_single.hpp (bf16; default 1) */
 int mcg_engine_set_option(mcg_engine* e, const char* name, int value);
 /* chunk_frames: the trunk runs in chunks of this many frames so that layer outputs stay
  * resident in the 256 MiB Infinity Cache (0 = all frames in one pass). */
