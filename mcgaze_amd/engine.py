@@ -337,7 +337,9 @@ class PipelinedRunner:
     (4 x [RoIAlign + stage] + gaze head: ~110 short, latency-bound launches) runs on a second HIP stream and
     overlaps the trunk of batch k+1, whose large contraction kernels leave CUs idle only at their tails.
     Pyramids are double-buffered; trunks serialise on stream A, decoders on stream B, ordered by events.
-    Every submitted batch is fully processed once ``flush()`` returns control to the caller's stream."""
+    Every submitted batch is fully processed once ``flush()`` returns control to the caller's stream.  A loop that owns the runner
+    should submit from ``runner.sa`` itself (``with torch.cuda.stream(runner.sa): ...``): the caller-stream -> trunk-stream hand-over
+    of each submit is then no cross-queue dependency (2 ms per pipeline fill + drain when the queues are idle; bench.py does this)."""
 
     def __init__(self, engine, num_frames, H, W, clip_length, chunk_frames=0, decoder_priority=-1):
         self.e, self.N, self.H, self.W, self.T, self.chunk = engine, num_frames, H, W, clip_length, chunk_frames
