@@ -448,7 +448,7 @@ def main():
                                    f'{B} clips/GPU x {T} frames x 3x{a.size}x{a.size}, {total_per_step} clips/step',
                        'clips_per_gpu': B, 'clip_length': T, 'global_clips': total_per_step, 'chunk_frames': a.chunk_frames,
                        'parallelism': f'dp{world} (clips sharded by rank, one fused all_gather of results per step)' if world > 1 else 'single GPU',
-                       'batch_pipeline': 'decoder(step k) overlaps trunk(step k+1) on a second HIP stream; all K batches complete inside the timed region' if (a.pipeline and a.workload == 'full') else 'none (serial)',
+                       'batch_pipeline': 'decoder(step k) overlaps trunk(step k+1) on a second HIP stream; the loop submits from the trunk stream; all K batches complete inside the timed region' if (a.pipeline and a.workload == 'full') else 'none (serial)',
                        'trunk_streams': a.trunk_streams},
             'timed_region_s': round(elapsed, 3),
             'verified': verified,
