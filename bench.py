@@ -12,7 +12,7 @@ One run reports, in ONE JSON line printed by rank 0:
   * the headline: the --precision engine (default bf16, the configuration north_star's roofline target is quoted on);
   * `verified`: after the timed loop, the last batch is re-run strictly serially (one trunk stream, no batch pipeline) and
     must reproduce the timed schedule's outputs BIT FOR BIT;
-  * `parity_engine`: the bf16x3 engine (f32 activations, split-bf16 x 3 MFMA contraction -- the engine that meets north_star's
+  * `parity_engine`: the f16x3 engine (f32 activations, split-fp16 x 3 MFMA contraction -- the engine that meets north_star's
     1e-3 on (yaw, pitch)) timed the same way, with its measured deviation from the CPU oracle on clip 0;
   * `roofline`: dominant contraction kernel, from HIP events around every contraction launch of one UNTIMED sampling step;
   * `latency_single_clip`: one 7-frame clip per forward (BASELINE.json configs[0], the reference harness's actual usage);
@@ -51,7 +51,7 @@ CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,
              27: 'igemm_dma_kernel<bf16,128,128,64,4,2,2>', 28: 'igemm_dma_kernel<bf16,256,256,64,4,4,3>',
              30: 'igemm_dma_kernel<bf16,256,256,128,4,4,2>', 31: 'igemm_dma_kernel<bf16,128,128,64,4,2,3>', 40: 'conv3x3_c64_kernel', 60: 'pw_pair_kernel (conv3 + next conv1, layer1)',
              61: 'pw_single_kernel (HBM-bound 1x1 convs, register-resident weights)', 62: 'pw_single_kernel<16,2,0,128> (dynamic_layer)',
-             # bf16x3 contraction (f32 activations, split-packed weights, 3 bf16 MFMAs per product)
+             # f16x3 contraction (f32 activations, split-packed weights, 3 fp16 MFMAs per product)
              50: 'igemm_dma_kernel<float,256,256,128,4,2,2,2,x3>', 51: 'igemm_dma_kernel<float,128,128,128,2,2,2,2,x3>', 52: 'igemm_dma_kernel<float,256,64,128,4,1,2,2,x3>'}
 
 
@@ -65,8 +65,8 @@ def parse():
                     help='strong scaling: a FIXED number of clips per step, sharded over the ranks (e.g. 512 = BASELINE.json configs[3]); 0 = weak scaling with --clips-per-gpu')
     ap.add_argument('--clip-length', type=int, default=7)
     ap.add_argument('--size', type=int, default=224)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
-    ap.add_argument('--parity-engine', default='bf16x3', choices=['bf16x3', 'fp32', 'none'],
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'f16x3'])
+    ap.add_argument('--parity-engine', default='f16x3', choices=['f16x3', 'fp32', 'none'],
                     help='second engine timed in the same run (the one that meets the 1e-3 parity tolerance); skipped when equal to --precision')
     ap.add_argument('--parity-steps', type=int, default=0, help='timed steps of the parity engine (0 = max(10, steps // 4))')
     ap.add_argument('--chunk-frames', type=int, default=0)
@@ -301,9 +301,9 @@ def roofline_of(rec, precision):
          'sampled': 'every contraction launch of one UNTIMED step after warm-up, HIP events on the launch stream, trunk on one stream '
                     '(trunk_streams=1) so a launch\'s duration is its own; the timed steps run two frame ranges on concurrent streams',
          'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_bench_traffic.sh); bytes per launch'}
-    if precision == 'bf16x3':
-        r['note'] = ('achieved = ALGORITHMIC FLOP/s; the bf16x3 contraction issues three bf16 MFMAs per algorithmic product, so the matrix pipe runs at '
-                     f'{round(3 * achieved, 1)} TFLOP/s = {round(3 * achieved / peak, 4)} of the bf16 peak')
+    if precision == 'f16x3':
+        r['note'] = ('achieved = ALGORITHMIC FLOP/s; the f16x3 contraction issues three fp16 MFMAs per algorithmic product, so the matrix pipe runs at '
+                     f'{round(3 * achieved, 1)} TFLOP/s = {round(3 * achieved / peak, 4)} of the 16-bit MFMA peak')
     if step_bytes:
         r['hbm_step'] = {'bytes': int(step_bytes), 'contraction_launches_covered': covered, 'of': len(rec), 'peak_GBps': PEAK_HBM_GBPS,
                          'note': 'divide by ms_per_step for the whole-path HBM rate; stem, RoIAlign and the small decoder kernels are not in it'}
@@ -428,8 +428,8 @@ def main():
                   'verified': pver, 'model_tflops': round(pval * FLOPS_PER_CLIP / 1e12, 1),
                   'max_abs_dev_yaw_pitch_clip0': deviation(pleg.outs[0], want_yp, T) if want_yp is not None else None,
                   'tolerance': PARITY_TOL, 'oracle': 'oracle/mcgaze_oracle.py (fp32 CPU restatement pinned to the reference goldens) on clip 0 of this batch',
-                  'what': 'f32 activations, split-packed bf16 weights, three bf16 MFMAs per product, f32 accumulate (include/mcgaze_hip.h MCG_BF16X3)'
-                          if a.parity_engine == 'bf16x3' else 'f32 storage and f32 MFMA',
+                  'what': 'f32 activations, weights split-packed into fp16 high / low halves, three fp16 MFMAs per product, f32 accumulate (include/mcgaze_hip.h MCG_F16X3)'
+                          if a.parity_engine == 'f16x3' else 'f32 storage and f32 MFMA',
                   'roofline': proof}
         del pleg
 

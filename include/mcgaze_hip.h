@@ -14,8 +14,8 @@
  *   - no allocation on the hot path: scratch comes from a caller-provided workspace
  *   - return value: MCG_OK or an MCG_ERR_* code; mcg_last_error() gives the message
  *   - activations are NHWC ("channels last"): [frame][y][x][channel]; dtype is MCG_F32
- *     (reference mode, f32 MFMA, exact f32 accumulate chains), MCG_BF16X3 (parity-grade fast
- *     mode: f32 storage, split-bf16 x 3 MFMA contraction) or MCG_BF16 (throughput mode,
+ *     (reference mode, f32 MFMA, exact f32 accumulate chains), MCG_F16X3 (parity-grade fast
+ *     mode: f32 storage, split-fp16 x 3 MFMA contraction) or MCG_BF16 (throughput mode,
  *     bf16 storage and MFMA, f32 accumulate).  Bias / LayerNorm parameters / boxes are always f32.
  *   - conv / linear weights are "OHWI": [Cout][KH][KW][Cin] (K contiguous), BN folded in.
  */
@@ -29,15 +29,17 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 6
+#define MCG_ABI_VERSION 7
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
-/* MCG_BF16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
+/* MCG_F16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
  * f32 storage); only the contraction differs: every conv / linear weight matrix is handed over SPLIT-PACKED -- per 8 consecutive
- * K elements a 16-byte chunk of bf16 high parts followed by a 16-byte chunk of bf16 low parts (w = hi + lo, lo = bf16(w - hi);
- * 4 bytes per element like f32) -- the f32 activations are split the same way in registers, and each product runs as three bf16
- * MFMAs (hi.hi + hi.lo + lo.hi) with f32 accumulation.  3-5e-5 rad on (yaw, pitch) against the reference (north_star: 1e-3). */
-typedef enum { MCG_F32 = 0, MCG_BF16 = 1, MCG_BF16X3 = 2 } mcg_dtype;
+ * K elements a 16-byte chunk of fp16 HIGH parts followed by a 16-byte chunk of fp16 LOW parts (w = hi + lo, lo = f16(w - hi):
+ * 22 significant bits; 4 bytes per element like f32) -- the f32 activations are split the same way in registers (round toward zero,
+ * x - hi exact), and each product runs as three fp16 MFMAs (lo.hi + hi.lo + hi.hi) with f32 accumulation.  Operands beyond
+ * +-65504 saturate per half (the reference's activations are orders of magnitude below); parts below 6e-8 flush to zero.
+ * Measured: 1e-5 rad on (yaw, pitch) against the reference (north_star: 1e-3), within a factor 2 of the MCG_F32 engine. */
+typedef enum { MCG_F32 = 0, MCG_BF16 = 1, MCG_F16X3 = 2 } mcg_dtype;
 typedef void* mcg_stream; /* hipStream_t */
 
 int mcg_abi_version(void);
@@ -83,7 +85,7 @@ typedef struct {
    * resnet.py:289-298): x2 = the block input, w2 = the BN-folded downsample weight. */
   const void* x2;       /* NHWC [N,H2,W2,Cin2] or NULL */
   int Cin2, stride2, H2, W2;
-  int tile;             /* 0 = heuristic; else force this tile id of the contraction kernel (igemm.hip: 9, 11, 12, 14, 15; bf16x3: 50, 51) */
+  int tile;             /* 0 = heuristic; else force this tile id of the contraction kernel (igemm.hip: 9, 11, 12, 14, 15; f16x3: 50, 51) */
   int flags;            /* MCG_FLAG_* */
 } mcg_conv_desc;
 int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);

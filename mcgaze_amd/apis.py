@@ -1,7 +1,7 @@
 """``init_detector`` with the reference's semantics (mmdet/apis/inference.py:17-57): build from a
 config file or Config, drop train_cfg / pretrained init, load the checkpoint with the key rewrite
 ``^module\\.`` -> '' (and the leftover ``mask_head`` -> ``blink_head`` rule), set ``model.cfg`` and
-``model.CLASSES``, move to the device, ``eval()``.  ``precision`` selects the HIP engine: 'bf16x3' (default, parity-grade
+``model.CLASSES``, move to the device, ``eval()``.  ``precision`` selects the HIP engine: 'f16x3' (default, parity-grade
 fast mode: the reference is fp32 everywhere and this mode reproduces it to < 1e-4 rad), 'fp32' (exact reference mode) or
 'bf16' (throughput mode, explicit opt-in: outside the 1e-3 parity tolerance on random-weight nets)."""
 import re
@@ -29,7 +29,7 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False, revise_ke
     return ckpt
 
 
-def init_detector(config, checkpoint=None, device='cuda:0', cfg_options=None, precision='bf16x3'):
+def init_detector(config, checkpoint=None, device='cuda:0', cfg_options=None, precision='f16x3'):
     if isinstance(config, str):
         config = Config.fromfile(config)
     elif not isinstance(config, Config):

@@ -136,7 +136,7 @@ static inline size_t esize(mcg_dtype dt) { return dt == MCG_BF16 ? 2 : 4; }
 extern "C" void mcg_engine_destroy(mcg_engine* e);
 extern "C" int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, mcg_dtype dt) {
   MCG_CHECK_ARG(out && w, "mcg_engine_create: null pointer");
-  MCG_CHECK_ARG(dt == MCG_F32 || dt == MCG_BF16 || dt == MCG_BF16X3, "mcg_engine_create: unknown dtype %d", (int)dt);
+  MCG_CHECK_ARG(dt == MCG_F32 || dt == MCG_BF16 || dt == MCG_F16X3, "mcg_engine_create: unknown dtype %d", (int)dt);
   int expect = 0;
   for (int l = 0; l < 4; ++l) {
     MCG_CHECK_ARG(w->blocks[l] > 0, "mcg_engine_create: blocks[%d]=%d", l, w->blocks[l]);

@@ -143,15 +143,15 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups, const M
   return MCG_OK;
 }
 
-// MCG_BF16X3: f32 activations x split-packed bf16 weights, three bf16 MFMAs per product (igemm_dma.hpp, X3 mode).
+// MCG_F16X3: f32 activations x split-packed fp16 weights, three fp16 MFMAs per product (igemm_dma.hpp, X3 mode).
 //   50 = 256x256 8 waves (64x128 wave tiles: the A split is shared by four column tiles), 2 stages, 128 KiB -- deep, wide layers
 //   51 = 128x128 4 waves, 2 stages, 64 KiB (two workgroups per CU) -- Cout < 256, few rows (7x7 maps, decoder linears)
 //   52 = 256x64 4 waves -- Cout <= 64
 static int launch_x3(hipStream_t s, const IgemmParams& p, int groups, const McgCtx& ctx) {
-  MCG_CHECK_ARG(p.Cin % 32 == 0 && (!p.x2 || p.Cin2 % 32 == 0), "igemm (bf16x3): Cin=%d must be a multiple of 32", p.Cin);
-  MCG_CHECK_ARG(p.Cout % 4 == 0, "igemm (bf16x3): Cout=%d must be a multiple of 4", p.Cout);
+  MCG_CHECK_ARG(p.Cin % 32 == 0 && (!p.x2 || p.Cin2 % 32 == 0), "igemm (f16x3): Cin=%d must be a multiple of 32", p.Cin);
+  MCG_CHECK_ARG(p.Cout % 4 == 0, "igemm (f16x3): Cout=%d must be a multiple of 4", p.Cout);
   if (!dma_eligible(p, 4)) {
-    mcg_set_error("igemm (bf16x3): operand beyond the 2 GiB descriptor window or more than 32 taps (M=%d Cin=%d %dx%d)", p.M, p.Cin, p.KH, p.KW);
+    mcg_set_error("igemm (f16x3): operand beyond the 2 GiB descriptor window or more than 32 taps (M=%d Cin=%d %dx%d)", p.M, p.Cin, p.KH, p.KW);
     return MCG_ERR_UNSUPPORTED;
   }
   const long long t256 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
@@ -162,13 +162,13 @@ static int launch_x3(hipStream_t s, const IgemmParams& p, int groups, const McgC
   else if (tile == 51) launch_dma<float, 128, 128, 128, 2, 2, 2, 2, 1>(s, p, groups);
   else launch_dma<float, 256, 64, 128, 4, 1, 2, 2, 1>(s, p, groups);
   prof_end(rec, s);
-  MCG_CHECK_LAUNCH("igemm (bf16x3) launch");
+  MCG_CHECK_LAUNCH("igemm (f16x3) launch");
   return MCG_OK;
 }
 
 int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p, int groups, const McgCtx& ctx) {
   MCG_CHECK_ARG(p.M > 0 && p.Cout > 0 && groups > 0, "igemm: empty problem (M=%d Cout=%d groups=%d)", p.M, p.Cout, groups);
-  if (dt == MCG_BF16X3) return launch_x3(s, p, groups, ctx);
+  if (dt == MCG_F16X3) return launch_x3(s, p, groups, ctx);
   return dt == MCG_BF16 ? launch_typed<bf16_t>(s, p, groups, ctx) : launch_typed<float>(s, p, groups, ctx);
 }
 
@@ -196,8 +196,8 @@ int launch_linear_splitk(hipStream_t s, mcg_dtype dt, const void* x, long long l
   IgemmParams p = linear_params(x, lda, w, M, K, Cout);
   const int es = dt == MCG_BF16 ? 2 : 4;
   const bool dma = dt == MCG_BF16 && !ctx.staged;
-  // K elements per K-tile of the kernel that will run: 32 (bf16x3), 64-byte slices (bf16 DMA), 128- or 64-byte slices (register-staged)
-  const int bk = dt == MCG_BF16X3 ? 32 : (dma ? 64 : (((long long)K * es) % 128 == 0 ? 128 : 64)) / es;
+  // K elements per K-tile of the kernel that will run: 32 (f16x3), 64-byte slices (bf16 DMA), 128- or 64-byte slices (register-staged)
+  const int bk = dt == MCG_F16X3 ? 32 : (dma ? 64 : (((long long)K * es) % 128 == 0 ? 128 : 64)) / es;
   const int KT = K / bk;
   int slices = want_slices < 1 ? 1 : (want_slices > KT ? KT : want_slices);
   const int per = (KT + slices - 1) / slices;
@@ -337,8 +337,8 @@ int stem_forward_ctx(hipStream_t s, mcg_dtype dt, const float* img, const void* 
     if (launch_stem_fused(s, img, w_stem, bias, y, N, H, W)) { mcg_set_error("stem_fused launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
   }
-  if (dt == MCG_BF16X3 && ctx.stem_fused) {  // the bf16x3 form of the same kernel; bit-identical to the three launches below
-    if (launch_stem_fused_x3(s, img, w_stem, bias, y, N, H, W)) { mcg_set_error("stem_fused (bf16x3) launch failed"); return MCG_ERR_HIP; }
+  if (dt == MCG_F16X3 && ctx.stem_fused) {  // the f16x3 form of the same kernel; bit-identical to the three launches below
+    if (launch_stem_fused_x3(s, img, w_stem, bias, y, N, H, W)) { mcg_set_error("stem_fused (f16x3) launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
   }
   const size_t es = dt == MCG_BF16 ? 2 : 4;

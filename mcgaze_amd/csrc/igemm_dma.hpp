@@ -71,28 +71,39 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // Eight f32 values (two 16-byte chunks) -> bf16 high parts and bf16 low parts: hi = RNE(x), lo = RNE(x - float(hi)); the
 // subtraction is exact (Sterbenz), so hi + lo = x to 2^-17 relative.
+typedef __fp16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// Two f32 -> their fp16 HIGH parts and fp16 LOW parts, packed: hi = RTZ_f16(x), lo = RTZ_f16(x - hi).  x - hi is exact, so hi + lo = x
+// to 2^-21 relative (22 significant bits) for |x| in [6e-5 * 2^11, 65504]; below that the low part is a subnormal half (absolute error
+// <= 6e-8), above it the halves saturate at +-65504 each (round toward zero never produces an infinity from a finite value).
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& h, uint32_t& l) {
+  const f16x2_t hh = __builtin_amdgcn_cvt_pkrtz(a, b);
+  h = __builtin_bit_cast(uint32_t, hh);
+  l = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a - (float)hh[0], b - (float)hh[1]));
+}
+// one 32x32x16 product term of the split contraction (operands travel as 16-byte vectors; they hold eight halves)
+__device__ __forceinline__ f32x16 x3_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ void split_f32x8(const uint4& c0, const uint4& c1, bf16x8& hi, bf16x8& lo) {
   const uint32_t x[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
   uint32_t h[4], l[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float a = __uint_as_float(x[2 * q]), b = __uint_as_float(x[2 * q + 1]);
-    h[q] = pack2bf(a, b);
-    l[q] = pack2bf(a - __uint_as_float(h[q] << 16), b - __uint_as_float(h[q] & 0xffff0000u));
-  }
+  for (int q = 0; q < 4; ++q) split_pair(__uint_as_float(x[2 * q]), __uint_as_float(x[2 * q + 1]), h[q], l[q]);
   hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
   lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
 }
 
-// X3 != 0 (T = float): the "bf16x3" contraction of the MCG_BF16X3 engine.  Activations stay f32 in HBM and LDS; the weight
-// operand is the split-packed form (packing.py::split_pack: per 8 consecutive K elements a 16-byte chunk of bf16 HIGH parts,
-// then a 16-byte chunk of bf16 LOW parts, w = hi + lo to 2^-17 -- 4 bytes per element, so the DMA geometry is that of an f32
-// matrix).  An A fragment is split in registers the same way (hi = RNE_bf16(x), lo = RNE_bf16(x - hi), the difference is exact)
-// and each 32x32x16 product is three v_mfma_f32_32x32x16_bf16: lo.hi + hi.lo + hi.hi, f32 accumulate (the dropped lo.lo term is
-// 2^-18 relative).  Measured end to end: 3-5e-5 rad on (yaw, pitch) against the f32 oracle, at bf16 matrix-pipe rate / 3.
+// X3 != 0 (T = float): the "f16x3" contraction of the MCG_F16X3 engine.  Activations stay f32 in HBM and LDS; the weight
+// operand is the split-packed form (packing.py::split_pack: per 8 consecutive K elements a 16-byte chunk of fp16 HIGH parts,
+// then a 16-byte chunk of fp16 LOW parts, w = hi + lo to 2^-21 -- 4 bytes per element, so the DMA geometry is that of an f32
+// matrix).  An A fragment is split in registers (split_pair: hi = RTZ_f16(x), lo = RTZ_f16(x - hi), the difference is exact)
+// and each 32x32x16 product is three v_mfma_f32_32x32x16_f16: lo.hi + hi.lo + hi.hi, f32 accumulate (the dropped lo.lo term is
+// 2^-22 relative).  Measured end to end: 1e-5 rad on (yaw, pitch) against the f32 oracle, at the fp16 matrix-pipe rate / 3.  (The
+// first version split into bf16 halves -- 16 significant bits, 6e-5 rad -- at the same speed; fp16 halves carry 22.)
 template <typename T, int BM, int BN, int BKB, int WAVES_M, int WAVES_N, int STAGES, int MINW = 2, int X3 = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel(const IgemmParams p) {
-  static_assert(!X3 || (sizeof(T) == 4 && BKB == 128), "bf16x3 mode: f32 storage, 128-byte K slices (32 channels)");
+  static_assert(!X3 || (sizeof(T) == 4 && BKB == 128), "f16x3 mode: f32 storage, 128-byte K slices (32 channels)");
   constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
   constexpr int ES = (int)sizeof(T);
   constexpr int EPC = 16 / ES;
@@ -297,8 +308,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   const char* fb[CPR / 2];
 #pragma unroll
   for (int j2 = 0; j2 < CPR / 2; ++j2) {
-    // plain: K-chunk 2 j2 + half.  bf16x3: the lane's 8 channels of MFMA step j = j2 / 2 are chunks 4 j + 2 half + (j2 & 1): for A
-    // the first / last four f32 values, for W the bf16 high parts / low parts of the same 8 channels
+    // plain: K-chunk 2 j2 + half.  f16x3: the lane's 8 channels of MFMA step j = j2 / 2 are chunks 4 j + 2 half + (j2 & 1): for A
+    // the first / last four f32 values, for W the fp16 high parts / low parts of the same 8 channels
     const int chunk = X3 ? 4 * (j2 >> 1) + 2 * (lane >> 5) + (j2 & 1) : 2 * j2 + (lane >> 5);
     const int cb = (chunk ^ fkey) << 4;
     fa[j2] = smem + (wm * WTM + (lane & 31)) * BKB + cb;
@@ -325,15 +336,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = x3_mfma(al[i], bh[j], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = x3_mfma(ah[i], bl[j], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = x3_mfma(ah[i], bh[j], acc[i][j]);
       });
     } else if constexpr (SWP) {
       uint4 af[2][TM], bf[2][TN];

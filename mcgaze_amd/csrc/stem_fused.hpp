@@ -21,7 +21,7 @@
 // the input hides under the MFMA phase.  SQ counters (profiles/r01_g_stem.md) put the kernel at the VALU issue rate, not at
 // HBM: what is left is instruction count.
 #pragma once
-#include "common.hpp"
+#include "igemm_dma.hpp"
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
@@ -169,10 +169,10 @@ static inline int launch_stem_fused(hipStream_t s, const float* img, const void*
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same for the bf16x3 engine (f32 activations, split-packed weights, three MFMAs per product): NCHW f32 frame -> conv 7x7/s2
+// The same for the f16x3 engine (f32 activations, split-packed weights, three MFMAs per product): NCHW f32 frame -> conv 7x7/s2
 // + BN -> ReLU -> max-pool -> NHWC f32 in one kernel.  The three-kernel path costs that engine 1.38 ms per 448 frames (pack 0.11,
 // contraction 0.87, pool 0.39: the f32 conv map is 1.44 GB written and read back).  Differences from the bf16 kernel above:
-//   * the input window is split ONCE when it is parked in LDS -- hi = RNE_bf16(x), lo = RNE_bf16(x - hi) (split_f32x8's
+//   * the input window is split ONCE when it is parked in LDS -- fp16 high and low parts (split_pair, the contraction kernel's
 //     arithmetic) into two planes of [rows][40][4 ch] -- instead of once per fragment read;
 //   * a lane keeps the high AND low 16-byte chunks of its weight row for all 14 K-steps (112 VGPRs, from the split-packed matrix
 //     of packing.py::split_pack); each K-step issues lo.hi, hi.lo, hi.hi in the contraction kernel's order: bit-identical to it;
@@ -244,9 +244,9 @@ __global__ __launch_bounds__(256, 2) void stem_fused_x3_kernel(const float* __re
     for (int j = 0; j < TRIPS; ++j) {
       const int idx = tid + j * 256;
       if (idx < ITY * ITW) {
-        const uint32_t h01 = pack2bf(v[j][0], v[j][1]), h2 = pack2bf(v[j][2], 0.f);
-        const uint32_t l01 = pack2bf(v[j][0] - __uint_as_float(h01 << 16), v[j][1] - __uint_as_float(h01 & 0xffff0000u));
-        const uint32_t l2 = pack2bf(v[j][2] - __uint_as_float(h2 << 16), 0.f);
+        uint32_t h01, l01, h2, l2;
+        split_pair(v[j][0], v[j][1], h01, l01);
+        split_pair(v[j][2], 0.f, h2, l2);
         *(uint2*)(s_hi + idx * 8) = make_uint2(h01, h2);
         *(uint2*)(s_lo + idx * 8) = make_uint2(l01, l2);
       }
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(256, 2) void stem_fused_x3_kernel(const float* __re
         const int off = a0 + ((ks >> 1) * ITW + (ks & 1) * 4) * 8;
         const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(s_hi + off));
         const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(s_lo + off));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc, 0, 0, 0);
+        acc = x3_mfma(al, bh[ks], acc);
+        acc = x3_mfma(ah, bl[ks], acc);
+        acc = x3_mfma(ah, bh[ks], acc);
       }
       const int mbase = mb * 32 + 4 * half;
       float* crow = (float*)(s_conv + mbase * 256) + nb * 32 + row;

@@ -316,7 +316,7 @@ class MultiClueGaze(nn.Module):
     Extension (the reference never batches clips at inference): pass
     ``clip_length=T`` to treat the N frames as N/T independent clips (the semantics of the
     reference's ``forward_train``); without it the N frames form ONE clip, as in the reference.
-    ``precision`` is an attribute of the model: 'bf16x3' (DEFAULT: f32 activations, split-bf16 x 3 MFMA contraction -- meets the
+    ``precision`` is an attribute of the model: 'f16x3' (DEFAULT: f32 activations, split-fp16 x 3 MFMA contraction -- meets the
     reference's fp32 results to < 1e-4 rad on (yaw, pitch), i.e. the engine to evaluate a checkpoint with), 'fp32' (f32 MFMA,
     the exact reference mode) or 'bf16' (throughput mode; an explicit opt-in, its deviation from the fp32 reference is not
     within the 1e-3 parity tolerance)."""
@@ -333,7 +333,7 @@ class MultiClueGaze(nn.Module):
         rcnn_train_cfg = train_cfg.get('rcnn') if train_cfg is not None else None
         self.roi_head = build_head(dict(roi_head, train_cfg=rcnn_train_cfg, test_cfg=(test_cfg or {}).get('rcnn'), pretrained=pretrained))
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
-        self.precision = 'bf16x3'   # a deliberate default: the reference computes in fp32 (mmdet/models/detectors/base.py:19, fp16_enabled = False)
+        self.precision = 'f16x3'   # a deliberate default: the reference computes in fp32 (mmdet/models/detectors/base.py:19, fp16_enabled = False)
         self.chunk_frames = 0
         self._engine = None
         self._engine_key = None

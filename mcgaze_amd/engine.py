@@ -12,10 +12,10 @@ import torch
 from . import lib as L
 from .packing import PackedWeights
 
-# precision -> (storage dtype of activations, mcg_dtype code).  'bf16x3': f32 storage, split-bf16 x 3 MFMA contraction (parity-grade
-# fast mode, include/mcgaze_hip.h MCG_BF16X3)
-_TORCH_DT = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32, 'bf16x3': torch.float32}
-_CODE = {'bf16': L.MCG_BF16, 'fp32': L.MCG_F32, 'f32': L.MCG_F32, 'bf16x3': L.MCG_BF16X3}
+# precision -> (storage dtype of activations, mcg_dtype code).  'f16x3': f32 storage, split-fp16 x 3 MFMA contraction (parity-grade
+# fast mode, include/mcgaze_hip.h MCG_F16X3)
+_TORCH_DT = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32, 'f16x3': torch.float32}
+_CODE = {'bf16': L.MCG_BF16, 'fp32': L.MCG_F32, 'f32': L.MCG_F32, 'f16x3': L.MCG_F16X3}
 
 
 def _code(dtype):
@@ -64,7 +64,7 @@ def to_nchw(x_nhwc):
 def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual_mode=L.RES_NONE, x2=None, stride2=1, split=False,
            tile=0, flags=0):
     """x NHWC, w OHWI (same dtype), bias f32 -> NHWC.  mcg_conv2d.  With x2: w = [Cout,1,1,Cin+Cin2], x2 sampled at stride2.
-    split=True: the MCG_BF16X3 contraction -- x / residual f32, w given as f32 OHWI and split-packed here (packing.split_pack).
+    split=True: the MCG_F16X3 contraction -- x / residual f32, w given as f32 OHWI and split-packed here (packing.split_pack).
     tile / flags: mcg_conv_desc.tile (force a contraction tile) and MCG_FLAG_* (lib.FLAG_*)."""
     _require_gpu()
     lib = L.load()
@@ -83,7 +83,7 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual
                    residual.shape[1] if residual is not None else 0, residual.shape[2] if residual is not None else 0,
                    x2.data_ptr() if x2 is not None else None, Cin2, stride2, x2.shape[1] if x2 is not None else 0,
                    x2.shape[2] if x2 is not None else 0, tile, flags)
-    L.check(lib.mcg_conv2d(_stream(), L.MCG_BF16X3 if split else _code(x.dtype), C.byref(d)), 'mcg_conv2d')
+    L.check(lib.mcg_conv2d(_stream(), L.MCG_F16X3 if split else _code(x.dtype), C.byref(d)), 'mcg_conv2d')
     return y
 
 
@@ -92,7 +92,7 @@ def stem(img, w_stem, bias, dtype, flags=0, split=False):
     _require_gpu()
     lib = L.load()
     N, _, H, W = img.shape
-    code = L.MCG_BF16X3 if split else _code(dtype)
+    code = L.MCG_F16X3 if split else _code(dtype)
     ws = _ws(lib.mcg_stem_workspace_bytes(code, N, H, W), img.device)
     y = torch.empty(N, H // 4, W // 4, 64, dtype=dtype, device=img.device)
     L.check(lib.mcg_stem_forward(_stream(), code, _ptr(img.contiguous()), _ptr(w_stem), _ptr(bias), _ptr(y), N, H, W,
@@ -127,7 +127,7 @@ def stage_forward(stage_w, roi_feat, obj, boxes, clip_length, stds=(0.5, 0.5, 1.
     _require_gpu()
     lib = L.load()
     N = obj.shape[0]
-    dt = L.MCG_BF16X3 if split else _code(obj.dtype)   # split: stage_w from PackedWeights(split=True), f32 activations
+    dt = L.MCG_F16X3 if split else _code(obj.dtype)   # split: stage_w from PackedWeights(split=True), f32 activations
     ws = _ws(lib.mcg_stage_workspace_bytes(dt, N), obj.device)
     obj_out = torch.empty_like(obj)
     boxes_out = torch.empty(N, 3, 4, dtype=torch.float32, device=obj.device)
@@ -144,7 +144,7 @@ def gaze_head(gaze_w, obj, split=False):
     _require_gpu()
     lib = L.load()
     N = obj.shape[0]
-    dt = L.MCG_BF16X3 if split else _code(obj.dtype)
+    dt = L.MCG_F16X3 if split else _code(obj.dtype)
     ws = _ws(lib.mcg_gaze_head_workspace_bytes(dt, N), obj.device)
     out = torch.empty(4, N, 3, dtype=torch.float32, device=obj.device)
     L.check(lib.mcg_gaze_head(_stream(), dt, _table(gaze_w, L.GAZE_KEYS), _ptr(obj.contiguous()), N, _ptr(out), _ptr(ws), ws.numel()), 'mcg_gaze_head')
@@ -163,7 +163,7 @@ class HipEngine:
         self.code = _CODE[precision]
         self.precision = precision
         self.weights = PackedWeights(state_dict, depth=depth, num_stages=num_stages, dtype=self.dtype, device=self.device,
-                                     fuse_downsample=fuse_downsample, split=self.code == L.MCG_BF16X3)
+                                     fuse_downsample=fuse_downsample, split=self.code == L.MCG_F16X3)
         w = self.weights
         mk = lambda c: L.ConvWeights(c['w'].data_ptr(), c['bias'].data_ptr(), c['cin'], c['cout'], c['k'], c['stride'], c['pad'],
                                      c['wf'].data_ptr() if c.get('wf') is not None else None)

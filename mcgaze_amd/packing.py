@@ -61,14 +61,15 @@ def frag_major(w):
 
 
 def split_pack(w):
-    """f32 [..., K] -> bf16 [..., 2K], the weight operand of the MCG_BF16X3 contraction (include/mcgaze_hip.h): per 8 consecutive
-    K elements a 16-byte chunk of bf16 high parts, then a 16-byte chunk of bf16 low parts; hi = bf16(w), lo = bf16(w - hi)
-    (round to nearest even both times), so hi + lo = w to 2^-17 relative.  4 bytes per element, like the f32 matrix it replaces."""
+    """f32 [..., K] -> fp16 [..., 2K], the weight operand of the MCG_F16X3 contraction (include/mcgaze_hip.h): per 8 consecutive
+    K elements a 16-byte chunk of fp16 high parts, then a 16-byte chunk of fp16 low parts; hi = f16(w), lo = f16(w - hi), so
+    hi + lo = w to 2^-22 relative (values beyond +-65504 saturate per half; low parts below 6e-8 vanish).  4 bytes per element,
+    like the f32 matrix it replaces."""
     w = w.float()
     K = w.shape[-1]
     assert K % 8 == 0, f'split_pack: K={K} must be a multiple of 8'
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
+    hi = w.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (w - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
     lead = w.shape[:-1]
     v = torch.stack([hi.reshape(*lead, K // 8, 8), lo.reshape(*lead, K // 8, 8)], dim=-2)   # [..., K/8, 2, 8]
     return v.reshape(*lead, 2 * K).contiguous()
@@ -88,8 +89,8 @@ class PackedWeights:
     """Device-resident packed weights + the geometry tables the engine needs."""
 
     def __init__(self, state_dict, depth=50, num_stages=4, dtype=torch.bfloat16, device='cuda:0', fuse_downsample=True, split=False):
-        """``dtype``: storage type of activations (and of the matrices for MCG_F32 / MCG_BF16).  ``split=True`` (MCG_BF16X3, dtype
-        must be float32): every conv / linear matrix is split-packed bf16 (``split_pack``) over its flattened K = (kh, kw, cin)."""
+        """``dtype``: storage type of activations (and of the matrices for MCG_F32 / MCG_BF16).  ``split=True`` (MCG_F16X3, dtype
+        must be float32): every conv / linear matrix is split-packed fp16 (``split_pack``) over its flattened K = (kh, kw, cin)."""
         sd = normalize_state_dict(state_dict)
         self.dtype, self.device, self.depth, self.num_stages, self.split = dtype, torch.device(device), depth, num_stages, split
         assert not split or dtype == torch.float32

@@ -33,7 +33,7 @@ def stage_report(eng, prec, sd, img, metas, T, stages):
     teacher_forced = [obj error of scale per stage, engine stage fed with the ORACLE's inputs],
     free_running   = [(level flips, boxes with a sample-validity flip, obj error of scale, max box |d| px) per stage],
     discontinuity  = whether the engine's own chain crossed a level / validity boundary the oracle's did not)."""
-    split = prec == 'bf16x3'
+    split = prec == 'f16x3'
     pyr = eng.backbone_fpn(torch.from_numpy(np.ascontiguousarray(img)).to(eng.device))
     hs, ws = [p.shape[1] for p in pyr], [p.shape[2] for p in pyr]
     boxes0, obj0 = orc.init_proposals(orc.as_torch(sd), metas)

@@ -177,15 +177,19 @@ def test_checkpoint_ingestion_envelope_and_key_rewrite(tmp_path):
 
 
 def test_split_pack_layout_and_accuracy():
-    """packing.split_pack (the MCG_BF16X3 weight operand): per 8 K elements 8 bf16 high parts then 8 bf16 low parts; hi + lo
-    reproduces the f32 value to 2^-17 relative."""
+    """packing.split_pack (the MCG_F16X3 weight operand): per 8 K elements 8 fp16 high parts then 8 fp16 low parts; hi + lo
+    reproduces the f32 value to 2^-21 relative where the low part is a normal half, to 6e-8 absolute below that, and saturates
+    per half beyond +-65504."""
     from mcgaze_amd.packing import split_pack
     g = torch.Generator().manual_seed(5)
     w = torch.randn(6, 64, generator=g) * torch.logspace(-6, 3, 64)[None, :]
     p = split_pack(w)
-    assert p.dtype == torch.bfloat16 and tuple(p.shape) == (6, 128)
+    assert p.dtype == torch.float16 and tuple(p.shape) == (6, 128)
     v = p.reshape(6, 8, 2, 8).float()
     hi, lo = v[:, :, 0, :].reshape(6, 64), v[:, :, 1, :].reshape(6, 64)
-    assert torch.equal(hi, w.to(torch.bfloat16).float())
-    assert torch.equal(lo, (w - hi).to(torch.bfloat16).float())
-    assert ((hi + lo - w).abs() <= w.abs() * 2.0 ** -17).all()
+    assert torch.equal(hi, w.to(torch.float16).float())
+    assert torch.equal(lo, (w - hi).to(torch.float16).float())
+    err = (hi + lo - w).abs()
+    assert (err <= torch.maximum(w.abs() * 2.0 ** -21, torch.tensor(2.0 ** -24))).all()
+    big = split_pack(torch.tensor([[1e6, -7e4, 65504.0, 3e-9, 0.0, 1.0, -1.0, 100000.0]])).float().reshape(2, 8)
+    assert torch.isfinite(big).all() and big[0, 0] == 65504.0 and big[1, 0] == 65504.0 and big[0, 3] == 0.0

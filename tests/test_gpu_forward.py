@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 F32_TOL = 1e-3    # north_star
 # bf16 THROUGHPUT engine, RANDOM-weight nets: bounds = the largest measured deviation x 1.3 (it is NOT within north_star's 1e-3; the
-# bf16x3 engine is).  Goldens (224x224 clips): 0.164 rad measured; unusual shapes (64x64 frames, 101-frame clip): 0.244 rad measured.
+# f16x3 engine is).  Goldens (224x224 clips): 0.164 rad measured; unusual shapes (64x64 frames, 101-frame clip): 0.244 rad measured.
 BF16_TOL = 0.215
 BF16_TOL_UNUSUAL = 0.32
 CASES = ['clip224', 'clip_nonsquare', 'batch2', 'clip_t5']
@@ -42,24 +42,24 @@ def load_case(golden_dir, name):
 def engines():
     from mcgaze_amd.engine import HipEngine
     sd = synth.make_state_dict(0)
-    return {p: HipEngine(sd, precision=p) for p in ('fp32', 'bf16', 'bf16x3')}
+    return {p: HipEngine(sd, precision=p) for p in ('fp32', 'bf16', 'f16x3')}
 
 
 @pytest.fixture(scope='module')
 def engines_by_weights(engines):
-    """weight seed -> (state dict, {'fp32', 'bf16x3'} engines); seed 0 reuses the module's engines."""
+    """weight seed -> (state dict, {'fp32', 'f16x3'} engines); seed 0 reuses the module's engines."""
     from mcgaze_amd.engine import HipEngine
     cache = {0: (synth.make_state_dict(0), engines)}
 
     def get(wseed):
         if wseed not in cache:
             sd = synth.make_state_dict(wseed)
-            cache[wseed] = (sd, {p: HipEngine(sd, precision=p) for p in ('fp32', 'bf16x3')})
+            cache[wseed] = (sd, {p: HipEngine(sd, precision=p) for p in ('fp32', 'f16x3')})
         return cache[wseed]
     return get
 
 
-PARITY_ENGINES = ['fp32', 'bf16x3']   # both must meet north_star's 1e-3; bf16x3 is the one bench.py times as `parity_engine`
+PARITY_ENGINES = ['fp32', 'f16x3']   # both must meet north_star's 1e-3; f16x3 is the one bench.py times as `parity_engine`
 
 
 @pytest.mark.parametrize('precision', PARITY_ENGINES)
@@ -102,7 +102,7 @@ def test_batched_equals_per_clip_bitwise(engines):
     calls exactly (same kernels, same reduction order per output element)."""
     T, B = 7, 5
     img = torch.from_numpy(synth.make_clips(42, B, T)).to('cuda:0')
-    for p in ('fp32', 'bf16', 'bf16x3'):
+    for p in ('fp32', 'bf16', 'f16x3'):
         e = engines[p]
         whole = {k: v.clone() for k, v in e.forward(img, T).items()}
         for b in range(B):
@@ -283,7 +283,7 @@ def test_bf16_error_growth_per_stage(golden_dir, engines, name):
             assert flips == 0 and err < BF16_SMOOTH_OBJ_BOUND and berr < BF16_SMOOTH_BOX_BOUND, (s, err, berr)
         ref_boxes_in = torch.from_numpy(g['stage_boxes'][s])
     # the parity-grade engine follows the reference through every stage, routing included
-    e3 = engines['bf16x3']
+    e3 = engines['f16x3']
     pyr3 = e3.backbone_fpn(torch.from_numpy(img).to('cuda:0'))
     boxes3, obj3 = torch.from_numpy(g['init_boxes']).to('cuda:0'), e3.weights.init_feats[None].expand(N, 3, 256).contiguous()
     ref_boxes_in = torch.from_numpy(g['init_boxes'])
@@ -294,12 +294,12 @@ def test_bf16_error_growth_per_stage(golden_dir, engines, name):
         torch.cuda.synchronize()
         want = torch.from_numpy(g['stage_obj'][s])
         err = float((obj3.cpu() - want).abs().max() / want.abs().max())
-        print(f'{name} bf16x3 stage {s}: obj error = {err:.2e} of scale')
+        print(f'{name} f16x3 stage {s}: obj error = {err:.2e} of scale')
         assert err < 2e-4, (s, err)
         ref_boxes_in = torch.from_numpy(g['stage_boxes'][s])
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['bf16', 'f16x3'])
 def test_bench_schedule_is_bitwise_equal_to_per_clip_calls(precision):
     """Exactly what bench.py times at BASELINE.json configs[2]: 64 clips x 7 x 3 x 224 x 224 (448 frames), chunk_frames = 0 ->
     two concurrent frame ranges on probed side streams, the two-deep PipelinedRunner, and the result exchange on its own stream
@@ -346,7 +346,7 @@ def test_bench_schedule_is_bitwise_equal_to_per_clip_calls(precision):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['bf16', 'f16x3'])
 def test_graphed_forward_is_bit_identical(engines, precision):
     """The HIP-graph latency path (engine.GraphedForward: one graph launch per clip) against the eager call, on several clips and
     with per-frame img_shape; also a 16-clip batch (two concurrent frame ranges inside the graph: fork / join events are captured)."""
@@ -418,7 +418,8 @@ def test_parity_on_random_shapes_and_weights(engines_by_weights, index):
     a pyramid-level boundary) and (yaw, pitch) is singular at the poles, so the assertions are the ones that CAN hold for every
     input (tests/parity_tools.py): every stage's arithmetic on the oracle's own inputs within 1e-4 of scale; end to end the gaze
     VECTORS within 5e-4 rad and (yaw, pitch) within north_star's 1e-3 away from the poles -- unless the engine's chain crossed a
-    discontinuity, which is then reported (profiles/r02_j_parity_fuzz.md: 6 such inputs in 400, none for the fp32 engine)."""
+    discontinuity, which is then reported (profiles/r02_m_parity_fuzz.md: none in 1400 inputs since the halves are fp16; the bf16-halves
+    version crossed seven, profiles/r02_j_parity_fuzz.md)."""
     from tests import parity_tools as PT
     k = synth.fuzz_case(2, index)
     sd, engs = engines_by_weights(k['wseed'])
@@ -426,7 +427,7 @@ def test_parity_on_random_shapes_and_weights(engines_by_weights, index):
     _, ref = orc.forward(sd, k['img'], k['metas'], k['T'], collect=stages)
     N = k['B'] * k['T']
     hw = None if k['full'] else np.tile(np.array(k['img_shape'], dtype=np.int32), (N, 1))
-    for prec in ('fp32', 'bf16x3'):
+    for prec in ('fp32', 'f16x3'):
         e = engs[prec]
         out = e.forward(torch.from_numpy(k['img']).to('cuda:0'), k['T'], img_hw=hw)
         got = out['gaze'][0].cpu()
@@ -438,5 +439,5 @@ def test_parity_on_random_shapes_and_weights(engines_by_weights, index):
         print(f'fuzz case {index} {prec}: max angle {float(ang.max()):.2e} rad, max d(yaw, pitch) {float(d.max()):.2e}; {PT.describe(rep)}')
         if rep['discontinuity']:
             continue
-        assert float(ang.max()) < 5e-4, (prec, float(ang.max()))      # measured: fp32 <= 2.2e-5, bf16x3 <= 2.2e-4
+        assert float(ang.max()) < 5e-4, (prec, float(ang.max()))      # measured: fp32 <= 2.2e-5, f16x3 <= 2.2e-4
         assert not bool(away.any()) or float(d[away].max()) < F32_TOL, (prec, float(d[away].max()))

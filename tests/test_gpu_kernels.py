@@ -94,8 +94,8 @@ X3_TOL = 3e-5   # of the tensor's scale: operands carry 16-17 significant bits (
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv2d_bf16x3(eng, case):
-    """The MCG_BF16X3 contraction (f32 activations, split-packed weights, three bf16 MFMAs per product) against the UNQUANTISED
+def test_conv2d_f16x3(eng, case):
+    """The MCG_F16X3 contraction (f32 activations, split-packed weights, three fp16 MFMAs per product) against the UNQUANTISED
     f32 convolution: it must sit two orders of magnitude inside the plain bf16 kernel's error."""
     N, H, W, Cin, Cout, k, stride, pad, relu, resk = case
     g = torch.Generator().manual_seed(1000 + CONV_CASES.index(case))
@@ -119,12 +119,12 @@ def test_conv2d_bf16x3(eng, case):
                    residual=nhwc(res) if res is not None else None, residual_mode=mode, split=True)
     torch.cuda.synchronize()
     err = scale_err(y.permute(0, 3, 1, 2), ref.float())
-    print(f'bf16x3 conv {case}: {err:.2e} of scale')
+    print(f'f16x3 conv {case}: {err:.2e} of scale')
     assert err < X3_TOL, err
 
 
-def test_conv2d_bf16x3_randomized_shapes(eng):
-    """The randomized sweep of test_conv2d_randomized_shapes for the bf16x3 kernel (channel counts are multiples of 32: its K tile)."""
+def test_conv2d_f16x3_randomized_shapes(eng):
+    """The randomized sweep of test_conv2d_randomized_shapes for the f16x3 kernel (channel counts are multiples of 32: its K tile)."""
     rs = np.random.RandomState(4048)
     for trial in range(30):
         k = int(rs.choice([1, 1, 3, 3, 5]))
@@ -159,7 +159,7 @@ def test_conv2d_bf16x3_randomized_shapes(eng):
 
 
 @pytest.mark.parametrize('stride2', [1, 2])
-def test_conv3_plus_downsample_bf16x3(eng, stride2):
+def test_conv3_plus_downsample_f16x3(eng, stride2):
     g = torch.Generator().manual_seed(177 + stride2)
     N, Ho, Wo, planes, inpl, cout = 3, 9, 7, 128, 256, 512
     o2 = torch.randn(N, planes, Ho, Wo, generator=g)
@@ -307,7 +307,7 @@ def test_fused_stem_is_bit_identical_to_the_three_kernel_path(eng, sd, shape):
     torch.cuda.synchronize()
     assert a.shape == b.shape == (n, h // 4, w // 4, 64)
     assert torch.equal(a.view(torch.int16), b.view(torch.int16))
-    # the bf16x3 form (f32 activations, split-packed weights, 8 x 4 pooled tiles: 36x52 -> 9x13 is ragged in both directions)
+    # the f16x3 form (f32 activations, split-packed weights, 8 x 4 pooled tiles: 36x52 -> 9x13 is ragged in both directions)
     px = PackedWeights(sd, dtype=torch.float32, split=True)
     a = eng.stem(img, px.stem['w'], px.stem['bias'], torch.float32, flags=L.FLAG_NO_SPECIALISED, split=True).clone()
     b = eng.stem(img, px.stem['w'], px.stem['bias'], torch.float32, split=True)
@@ -416,23 +416,23 @@ def test_roi_align_hip_equals_scalar_statement(eng):
     assert worst < 2e-5
 
 
-KINDS = ['fp32', 'bf16x3', 'bf16']   # engine kinds of the whole-operator tests below
-KIND_DTYPE = {'fp32': torch.float32, 'bf16x3': torch.float32, 'bf16': torch.bfloat16}
+KINDS = ['fp32', 'f16x3', 'bf16']   # engine kinds of the whole-operator tests below
+KIND_DTYPE = {'fp32': torch.float32, 'f16x3': torch.float32, 'bf16': torch.bfloat16}
 # Per-operator bounds as a fraction of the tensor's scale: measured worst case over the parametrised cases x 1.5 (printed by the tests).
-# fp32: only the summation order differs from the CPU reference.  bf16x3: operands carry 16-17 bits.  bf16: 8 bits on operands and
+# fp32: only the summation order differs from the CPU reference.  f16x3: operands carry 16-17 bits.  bf16: 8 bits on operands and
 # stored activations.
 STAGE_TOL = {'fp32': dict(obj=2e-6, cls=2e-6, boxes=1e-6),          # measured <= 1.0e-6 / 1.3e-6 / 5.7e-7
-             'bf16x3': dict(obj=2.5e-5, cls=2.5e-5, boxes=1.2e-5),  # measured <= 1.3e-5 / 1.4e-5 / 7.0e-6
+             'f16x3': dict(obj=2.5e-5, cls=2.5e-5, boxes=1.2e-5),  # measured <= 1.3e-5 / 1.4e-5 / 7.0e-6
              'bf16': dict(obj=1.5e-2, cls=2e-2, boxes=6e-3)}        # measured <= 9.6e-3 / 1.3e-2 / 4.0e-3 (round 1 allowed 6e-2)
-GAZE_TOL = {'fp32': 2e-6, 'bf16x3': 4.5e-5, 'bf16': 4e-2}           # measured 1.1e-6 / 2.8e-5 / 2.7e-2 (absolute, unit vectors)
-PYRAMID_TOL = {'fp32': 4e-6, 'bf16x3': 3e-5, 'bf16': 1.7e-2}        # measured <= 2.6e-6 / 1.9e-5 / 1.13e-2 (round 1 allowed 5e-2)
+GAZE_TOL = {'fp32': 2e-6, 'f16x3': 4.5e-5, 'bf16': 4e-2}           # measured 1.1e-6 / 2.8e-5 / 2.7e-2 (absolute, unit vectors)
+PYRAMID_TOL = {'fp32': 4e-6, 'f16x3': 3e-5, 'bf16': 1.7e-2}        # measured <= 2.6e-6 / 1.9e-5 / 1.13e-2 (round 1 allowed 5e-2)
 
 
 @pytest.mark.parametrize('kind', KINDS)
 @pytest.mark.parametrize('B,T', [(1, 7), (2, 3), (3, 1)])
 def test_decoder_stage(eng, sd, kind, B, T):
     from mcgaze_amd.packing import PackedWeights
-    dtype, split = KIND_DTYPE[kind], kind == 'bf16x3'
+    dtype, split = KIND_DTYPE[kind], kind == 'f16x3'
     pw = PackedWeights(sd, dtype=dtype, split=split)
     N = B * T
     g = torch.Generator().manual_seed(100 + N)
@@ -479,7 +479,7 @@ def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T):
 @pytest.mark.parametrize('kind', KINDS)
 def test_gaze_head(eng, sd, kind):
     from mcgaze_amd.packing import PackedWeights
-    dtype, split = KIND_DTYPE[kind], kind == 'bf16x3'
+    dtype, split = KIND_DTYPE[kind], kind == 'f16x3'
     pw = PackedWeights(sd, dtype=dtype, split=split)
     obj = torch.randn(9, 3, 256, generator=torch.Generator().manual_seed(8))
     ref = orc.gaze_head(sd, 3, obj.to(dtype).float())

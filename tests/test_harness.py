@@ -190,7 +190,7 @@ def test_dataset_tool_end_to_end(tmp_path, monkeypatch, capsys):
 @pytest.mark.gpu
 def test_dataset_run_matches_the_cpu_oracle_end_to_end(tmp_path):
     """BASELINE.json configs[4] in miniature: frames on disk -> decode -> preprocessing (seeded random crop per window) -> windows ->
-    default engine (bf16x3) -> overlap merge -> MAE, against the same chain on the CPU: oracle preprocessing + oracle forward per
+    default engine (f16x3) -> overlap merge -> MAE, against the same chain on the CPU: oracle preprocessing + oracle forward per
     window (the reference's arithmetic, pinned by the goldens) + the same merge.  Gaze vectors within north_star's 1e-3 rad, the
     three MAE figures within 0.02 degrees (they are printed with two decimals)."""
     from PIL import Image
@@ -216,7 +216,7 @@ def test_dataset_run_matches_the_cpu_oracle_end_to_end(tmp_path):
         g = rs.randn(L, 3)
         anno['videos'].append(dict(id=vid, file_names=names))
         anno['annotations'].append(dict(gaze=(g / np.linalg.norm(g, axis=1, keepdims=True)).tolist()))
-    eng = HipEngine(sd, precision='bf16x3')
+    eng = HipEngine(sd, precision='f16x3')
     recs = harness.run_annotation(eng, anno, str(tmp_path), pipe, rng=np.random.RandomState(5))
     # ---- the CPU chain
     rng = np.random.RandomState(5)

@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 img = torch.from_numpy(synth.make_clips(5, 1, 7)).cuda()
 metas = synth.make_img_metas(7, (224, 224, 3))
-for prec in ('bf16x3', 'bf16', 'fp32'):
+for prec in ('f16x3', 'bf16', 'fp32'):
     model = init_detector(os.path.join(root, 'configs', 'mcgaze', 'r50_clip7_gaze360.py'), None, device='cuda:0', precision=prec)
     eng = model.engine()
     def api():

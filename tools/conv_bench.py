@@ -1,5 +1,5 @@
 """GPU tool: time one conv shape through mcg_conv2d.
-usage: conv_bench.py N H W Cin Cout k stride pad [iters] [residual] [tile] [precision bf16|bf16x3|fp32] [data randn|zeros|relu|small]"""
+usage: conv_bench.py N H W Cin Cout k stride pad [iters] [residual] [tile] [precision bf16|f16x3|fp32] [data randn|zeros|relu|small]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ tile = int(sys.argv[11]) if len(sys.argv) > 11 else 0
 prec = sys.argv[12] if len(sys.argv) > 12 else 'bf16'
 mode = sys.argv[13] if len(sys.argv) > 13 else 'randn'   # the rate depends on the operand bits: the kernel sits on the package power cap
 dt = torch.bfloat16 if prec == 'bf16' else torch.float32
-split = prec == 'bf16x3'
+split = prec == 'f16x3'
 x = torch.randn(N, H, W, Cin, device='cuda')
 if mode == 'zeros': x.zero_()
 elif mode == 'relu': x.relu_()

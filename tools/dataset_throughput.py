@@ -1,6 +1,6 @@
 """GPU tool: end-to-end rate of the dataset path (files -> decode -> device preprocessing -> windows -> engine -> merged records,
 harness.run_annotation) on a synthetic directory of JPEG frames, with the frames decoded in line and by the look-ahead thread pool.
-usage: python tools/dataset_throughput.py [videos=48] [frames_per_video=60] [side=360] [precision=bf16x3]"""
+usage: python tools/dataset_throughput.py [videos=48] [frames_per_video=60] [side=360] [precision=f16x3]"""
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +13,7 @@ from mcgaze_amd.pipeline import DevicePipeline
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 360
-prec = sys.argv[4] if len(sys.argv) > 4 else 'bf16x3'
+prec = sys.argv[4] if len(sys.argv) > 4 else 'f16x3'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pipe = DevicePipeline(Config.fromfile(os.path.join(root, 'configs', 'mcgaze', 'r50_clip7_gaze360.py')).data.test.pipeline)
 eng = HipEngine(synth.make_state_dict(0), precision=prec)

@@ -1,5 +1,5 @@
 """GPU probe: does the ORDER in which two engines are created and timed inside one process change their rates?
-(bench.py times the bf16 engine and then the bf16x3 engine; the second leg measured 12 % slower than alone.)
+(bench.py times the bf16 engine and then the f16x3 engine; the second leg measured 12 % slower than alone.)
 usage: python tools/leg_order_probe.py <order> [steps]   order = e.g. x3,x3 | bf16,x3 | x3,bf16 | bf16,del,x3"""
 import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,7 @@ for name in order:
     if name == 'del':
         legs.clear(); gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
         continue
-    prec = {'x3': 'bf16x3'}.get(name, name)
+    prec = {'x3': 'f16x3'}.get(name, name)
     leg = bench.Leg(a, prec, dev, 1, 0, None, img, 64, 7)
     legs.append(leg)
     t = leg.timed(steps, 5)

@@ -1,5 +1,5 @@
 """GPU probe: where does the bf16 engine's deviation come from?  For fuzz cases: (a) the bf16 engine, (b) bf16 trunk (pyramid converted to f32)
-+ bf16x3 decoder, (c) bf16x3 trunk (pyramid rounded to bf16) + bf16 decoder; angle between gaze vectors vs the oracle.
++ f16x3 decoder, (c) f16x3 trunk (pyramid rounded to bf16) + bf16 decoder; angle between gaze vectors vs the oracle.
 usage: python tools/mixed_precision_probe.py [cases=40] [seed=5]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 torch.set_num_threads(16)
 sds, engs = {}, {}
-res = {k: [] for k in ('bf16', 'bf16 trunk + x3 decoder', 'x3 trunk + bf16 decoder', 'bf16x3', 'x3 trunk + fp32 decoder', 'fp32 trunk + x3 decoder', 'fp32')}
+res = {k: [] for k in ('bf16', 'bf16 trunk + x3 decoder', 'x3 trunk + bf16 decoder', 'f16x3', 'x3 trunk + fp32 decoder', 'fp32 trunk + x3 decoder', 'fp32')}
 
 def decode(eng, split, pyr, metas, sd, T):
     boxes, obj = orc.init_proposals(orc.as_torch(sd), metas)
@@ -31,15 +31,15 @@ for c in range(cases):
     w = k['wseed']
     if w not in sds:
         sds[w] = synth.make_state_dict(w)
-        engs[w] = {p: HipEngine(sds[w], precision=p) for p in ('bf16', 'bf16x3', 'fp32')}
+        engs[w] = {p: HipEngine(sds[w], precision=p) for p in ('bf16', 'f16x3', 'fp32')}
     _, ref = orc.forward(sds[w], k['img'], k['metas'], k['T'])
     x = torch.from_numpy(k['img']).cuda()
-    eb, ex, ef = engs[w]['bf16'], engs[w]['bf16x3'], engs[w]['fp32']
+    eb, ex, ef = engs[w]['bf16'], engs[w]['f16x3'], engs[w]['fp32']
     pb, px, pf = eb.backbone_fpn(x), ex.backbone_fpn(x), ef.backbone_fpn(x)
     g = {'bf16': decode(eb, False, pb, k['metas'], sds[w], k['T']),
          'bf16 trunk + x3 decoder': decode(ex, True, [p.float() for p in pb], k['metas'], sds[w], k['T']),
          'x3 trunk + bf16 decoder': decode(eb, False, [p.to(torch.bfloat16) for p in px], k['metas'], sds[w], k['T']),
-         'bf16x3': decode(ex, True, px, k['metas'], sds[w], k['T']),
+         'f16x3': decode(ex, True, px, k['metas'], sds[w], k['T']),
          'x3 trunk + fp32 decoder': decode(ef, False, px, k['metas'], sds[w], k['T']),
          'fp32 trunk + x3 decoder': decode(ex, True, pf, k['metas'], sds[w], k['T']),
          'fp32': decode(ef, False, pf, k['metas'], sds[w], k['T'])}
