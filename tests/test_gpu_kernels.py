@@ -90,7 +90,7 @@ def test_conv2d(eng, dtype, case):
     assert scale_err(y.permute(0, 3, 1, 2), ref) < TOL[dtype]
 
 
-X3_TOL = 3e-5   # of the tensor's scale: operands carry 16-17 significant bits (hi + lo), products hi.hi + hi.lo + lo.hi, f32 accumulate
+X3_TOL = 1.5e-6   # of the tensor's scale (measured <= 8.4e-7): operands carry 22 significant bits (fp16 hi + lo), products lo.hi + hi.lo + hi.hi, f32 accumulate
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
@@ -419,13 +419,14 @@ def test_roi_align_hip_equals_scalar_statement(eng):
 KINDS = ['fp32', 'f16x3', 'bf16']   # engine kinds of the whole-operator tests below
 KIND_DTYPE = {'fp32': torch.float32, 'f16x3': torch.float32, 'bf16': torch.bfloat16}
 # Per-operator bounds as a fraction of the tensor's scale: measured worst case over the parametrised cases x 1.5 (printed by the tests).
-# fp32: only the summation order differs from the CPU reference.  f16x3: operands carry 16-17 bits.  bf16: 8 bits on operands and
+# fp32: only the summation order differs from the CPU reference.  f16x3: operands carry 22 bits (bf16 halves, the first version: 16-17 bits,
+# bounds 2.5e-5 / 4.5e-5 / 3e-5).  bf16: 8 bits on operands and
 # stored activations.
 STAGE_TOL = {'fp32': dict(obj=2e-6, cls=2e-6, boxes=1e-6),          # measured <= 1.0e-6 / 1.3e-6 / 5.7e-7
-             'f16x3': dict(obj=2.5e-5, cls=2.5e-5, boxes=1.2e-5),  # measured <= 1.3e-5 / 1.4e-5 / 7.0e-6
+             'f16x3': dict(obj=3.5e-6, cls=4.5e-6, boxes=9e-7),    # measured <= 2.1e-6 / 3.0e-6 / 5.7e-7
              'bf16': dict(obj=1.5e-2, cls=2e-2, boxes=6e-3)}        # measured <= 9.6e-3 / 1.3e-2 / 4.0e-3 (round 1 allowed 6e-2)
-GAZE_TOL = {'fp32': 2e-6, 'f16x3': 4.5e-5, 'bf16': 4e-2}           # measured 1.1e-6 / 2.8e-5 / 2.7e-2 (absolute, unit vectors)
-PYRAMID_TOL = {'fp32': 4e-6, 'f16x3': 3e-5, 'bf16': 1.7e-2}        # measured <= 2.6e-6 / 1.9e-5 / 1.13e-2 (round 1 allowed 5e-2)
+GAZE_TOL = {'fp32': 2e-6, 'f16x3': 3.5e-6, 'bf16': 4e-2}           # measured 1.1e-6 / 2.2e-6 / 2.7e-2 (absolute, unit vectors)
+PYRAMID_TOL = {'fp32': 4e-6, 'f16x3': 5e-6, 'bf16': 1.7e-2}        # measured <= 2.6e-6 / 3.2e-6 / 1.13e-2 (round 1 allowed 5e-2)
 
 
 @pytest.mark.parametrize('kind', KINDS)
