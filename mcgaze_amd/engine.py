@@ -14,8 +14,9 @@ from .packing import PackedWeights
 
 # precision -> (storage dtype of activations, mcg_dtype code).  'f16x3': f32 storage, split-fp16 x 3 MFMA contraction (parity-grade
 # fast mode, include/mcgaze_hip.h MCG_F16X3)
-_TORCH_DT = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32, 'f16x3': torch.float32}
-_CODE = {'bf16': L.MCG_BF16, 'fp32': L.MCG_F32, 'f32': L.MCG_F32, 'f16x3': L.MCG_F16X3}
+_TORCH_DT = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32, 'f16x3': torch.float32, 'bf16x3': torch.float32}
+_CODE = {'bf16': L.MCG_BF16, 'fp32': L.MCG_F32, 'f32': L.MCG_F32, 'f16x3': L.MCG_F16X3,
+         'bf16x3': L.MCG_F16X3}   # 'bf16x3': the engine's name while its halves were bf16 -- accepted, runs the fp16-halves engine
 
 
 def _code(dtype):
