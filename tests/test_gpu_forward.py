@@ -418,8 +418,8 @@ def test_parity_on_random_shapes_and_weights(engines_by_weights, index):
     a pyramid-level boundary) and (yaw, pitch) is singular at the poles, so the assertions are the ones that CAN hold for every
     input (tests/parity_tools.py): every stage's arithmetic on the oracle's own inputs within 2e-5 of scale; end to end the gaze
     VECTORS within 2e-4 rad and (yaw, pitch) within north_star's 1e-3 away from the poles -- unless the engine's chain crossed a
-    discontinuity, which is then reported (profiles/r02_m_parity_fuzz.md: none in 1400 inputs since the halves are fp16; the bf16-halves
-    version crossed seven, profiles/r02_j_parity_fuzz.md)."""
+    discontinuity, which is then reported (profiles/r02_m_parity_fuzz.md: one in 2400 inputs since the halves are fp16; the bf16-halves
+    version crossed seven in 1400, profiles/r02_j_parity_fuzz.md)."""
     from tests import parity_tools as PT
     k = synth.fuzz_case(2, index)
     sd, engs = engines_by_weights(k['wseed'])
