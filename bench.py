@@ -9,14 +9,23 @@ of a FIXED G clips (strong scaling) -- and the per-rank results are exchanged wi
 all_gather per step.
 
 One run reports, in ONE JSON line printed by rank 0:
-  * the headline: the --precision engine (default bf16, the configuration north_star's roofline target is quoted on);
+  * the headline (`value`, `dtype`, `ms_per_step`, `roofline`): the --precision engine, default **f16x3** -- the engine that meets
+    north_star's 1e-3 on (yaw, pitch) (f32 activations, split-fp16 x 3 MFMA contraction; the library's default) -- with its
+    measured deviation from the CPU oracle on clip 0 (`max_abs_dev_yaw_pitch_clip0`, `within_tolerance`);
   * `verified`: after the timed loop, the last batch is re-run strictly serially (one trunk stream, no batch pipeline) and
     must reproduce the timed schedule's outputs BIT FOR BIT;
-  * `parity_engine`: the f16x3 engine (f32 activations, split-fp16 x 3 MFMA contraction -- the engine that meets north_star's
-    1e-3 on (yaw, pitch)) timed the same way, with its measured deviation from the CPU oracle on clip 0;
-  * `roofline`: dominant contraction kernel, from HIP events around every contraction launch of one UNTIMED sampling step;
+  * `throughput_engine`: the --second-engine (default bf16: 16-bit storage and MFMA) timed the same way, flagged
+    `within_tolerance: false` when its measured deviation exceeds the tolerance -- reported, never the headline;
+  * `roofline`: dominant contraction kernel, from HIP events around every contraction launch of one UNTIMED sampling step, with the
+    algorithmic HBM bytes of every launch beside the PMC traffic;
+  * `backbone`: BASELINE.json configs[1] -- R-50 backbone only at 32 clips x 7 frames, both engines;
+  * `mae_proxy`: synthetic videos -> device preprocessing -> 7-frame windows (stride 4) -> engine -> overlap merge -> smooth_filter
+    -> mean angular error (degrees), every engine against the fp32 CPU oracle's outputs taken as ground truth, and the SHIFT of
+    the MAE against a synthetic ground truth placed ~10.7 degrees from the oracle (north_star: within +-0.05 degrees);
   * `latency_single_clip`: one 7-frame clip per forward (BASELINE.json configs[0], the reference harness's actual usage);
-  * `cpu_baseline`: the fp32 oracle on the host cores (rank 0, N = 1 only), best thread count of a sweep, median of >= 10 forwards.
+  * `cpu_baseline`: the fp32 oracle on the host cores (rank 0, N = 1 only), best thread count of a sweep, median of >= 10 forwards;
+  * N > 1: `world_size` (torch.distributed's), `rccl_ranks_verified` (every rank recomputes clip 0 of its ring neighbour and compares
+    it bit for bit with what the all_gather delivered) and `strong_scaling` (a FIXED 512-clip batch sharded over the ranks).
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -65,10 +74,14 @@ def parse():
                     help='strong scaling: a FIXED number of clips per step, sharded over the ranks (e.g. 512 = BASELINE.json configs[3]); 0 = weak scaling with --clips-per-gpu')
     ap.add_argument('--clip-length', type=int, default=7)
     ap.add_argument('--size', type=int, default=224)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'f16x3'])
-    ap.add_argument('--parity-engine', default='f16x3', choices=['f16x3', 'fp32', 'none'],
-                    help='second engine timed in the same run (the one that meets the 1e-3 parity tolerance); skipped when equal to --precision')
-    ap.add_argument('--parity-steps', type=int, default=0, help='timed steps of the parity engine (0 = max(10, steps // 4))')
+    ap.add_argument('--precision', default='f16x3', choices=['bf16', 'fp32', 'f16x3'],
+                    help='the HEADLINE engine; f16x3 (default) is the one inside north_star\'s 1e-3 tolerance')
+    ap.add_argument('--second-engine', '--parity-engine', dest='second_engine', default='bf16', choices=['bf16', 'f16x3', 'fp32', 'none'],
+                    help='second engine timed in the same run and reported as a sub-object; skipped when equal to --precision')
+    ap.add_argument('--second-steps', '--parity-steps', dest='second_steps', type=int, default=0, help='timed steps of the second engine (0 = steps)')
+    ap.add_argument('--backbone-clips', type=int, default=32, help='BASELINE.json configs[1]: clips of the backbone-only sub-measurement (0 disables)')
+    ap.add_argument('--mae-videos', type=int, default=8, help='synthetic videos of the mae_proxy leg (rank 0, N = 1 only; 0 disables)')
+    ap.add_argument('--strong-clips', type=int, default=512, help='N > 1: fixed global batch of the strong-scaling sub-measurement (0 disables)')
     ap.add_argument('--chunk-frames', type=int, default=0)
     ap.add_argument('--workload', default='full', choices=['full', 'backbone_fpn', 'backbone'],
                     help="'full' = BASELINE.json configs[2] (the metric's configuration); 'backbone_fpn' = configs[1], the trunk alone "
@@ -159,17 +172,18 @@ def comm_stream(dev):
 class Leg:
     """One engine + its schedule (batch pipeline, result exchange) -- the thing a timed region runs."""
 
-    def __init__(self, a, precision, dev, world, rank, dist, img, B, T):
+    def __init__(self, a, precision, dev, world, rank, dist, img, B, T, workload=None, engine=None):
         from mcgaze_amd import synth
         from mcgaze_amd.engine import HipEngine, PipelinedRunner
         from mcgaze_amd.dist import ResultGather
         self.a, self.dev, self.dist, self.img, self.B, self.T, self.N = a, dev, dist, img, B, T, B * T
         self.precision = precision
-        self.eng = HipEngine(synth.make_state_dict(0), precision=precision, device=dev)
+        self.workload = workload or a.workload
+        self.eng = engine if engine is not None else HipEngine(synth.make_state_dict(0), precision=precision, device=dev)
         self.eng.set_option('trunk_streams', a.trunk_streams)
         self.gathers = [ResultGather(self.N, world, dev) for _ in range(2)]   # results double-buffered like the pipeline
         self.outs = [g.local_views() for g in self.gathers]                    # the engine writes straight into the fused exchange buffers
-        self.runner = PipelinedRunner(self.eng, self.N, a.size, a.size, T, a.chunk_frames) if a.pipeline and a.workload == 'full' else None
+        self.runner = PipelinedRunner(self.eng, self.N, a.size, a.size, T, a.chunk_frames) if a.pipeline and self.workload == 'full' else None
         # The result exchange runs on its own stream, ordered only after the decoder that produced the slot: on the caller's stream
         # it would sit between successive submits and serialise batch k+1's trunk behind batch k's decoder (the pipeline's whole point).
         self.comm = comm_stream(dev) if dist is not None else None
@@ -178,10 +192,10 @@ class Leg:
 
     def step(self):
         a, eng = self.a, self.eng
-        if a.workload == 'backbone_fpn':
+        if self.workload == 'backbone_fpn':
             eng.backbone_fpn(self.img, a.chunk_frames)
             return
-        if a.workload == 'backbone':
+        if self.workload == 'backbone':
             eng.backbone_only(self.img)
             return
         slot = self.k & 1
@@ -228,9 +242,9 @@ class Leg:
         eng.set_option('trunk_streams', 1)
         try:
             eng.profile_start(4096)
-            if a.workload == 'full':
+            if self.workload == 'full':
                 eng.forward(self.img, self.T, chunk_frames=a.chunk_frames)
-            elif a.workload == 'backbone_fpn':
+            elif self.workload == 'backbone_fpn':
                 eng.backbone_fpn(self.img, a.chunk_frames)
             else:
                 eng.backbone_only(self.img)
@@ -266,7 +280,7 @@ class Leg:
 
     def verify(self):
         """The timed schedule's last outputs (both pipeline slots) against the strictly serial schedule on the same batch: bitwise."""
-        if self.a.workload != 'full':
+        if self.workload != 'full':
             return None
         ref = self.serial_forward()
         slots = [0, 1] if self.k >= 2 else [0]
@@ -274,14 +288,15 @@ class Leg:
 
 
 def roofline_of(rec, precision):
+    """rec: engine.profile_stop() tuples (ms, algorithmic flops, cfg, (M, N, K), algorithmic HBM bytes) of ONE step's contraction launches."""
     by = {}
-    for t, f, c, _ in rec:
-        d = by.setdefault(c, [0.0, 0.0, 0])
-        d[0] += t; d[1] += f; d[2] += 1
+    for t, f, c, _, b in rec:
+        d = by.setdefault(c, [0.0, 0.0, 0, 0.0])
+        d[0] += t; d[1] += f; d[2] += 1; d[3] += b
     if not by:
         return None
     dom = max(by, key=lambda c: by[c][0])
-    t_ms, flops, n = by[dom]
+    t_ms, flops, n, abytes = by[dom]
     achieved = flops / (t_ms * 1e-3) / 1e12
     peak = PEAK_F32_TFLOPS if dom < 4 else PEAK_BF16_TFLOPS
     traffic, step_bytes, covered = None, 0.0, 0
@@ -293,19 +308,31 @@ def roofline_of(rec, precision):
             b = (tj.get(CFG_NAMES.get(c, '')) or {}).get('hbm_bytes_per_launch')
             if b:
                 step_bytes += b * v[2]; covered += v[2]
+    algo_step = sum(v[3] for v in by.values())
     r = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-         'traffic': traffic, 'kernel': CFG_NAMES.get(dom, str(dom)), 'launches_per_step': n,
+         'traffic': traffic, 'algorithmic_bytes_per_launch': int(abytes / n),
+         'traffic_over_algorithmic': round(traffic / (abytes / n), 3) if traffic else None,
+         'kernel': CFG_NAMES.get(dom, str(dom)), 'launches_per_step': n,
          'avg_launch_ms': round(t_ms / n, 4), 'algorithmic_gflop_per_launch': round(flops / n / 1e9, 2),
-         'all_contraction_launches': {CFG_NAMES.get(c, str(c)): {'launches': v[2], 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
+         'all_contraction_launches': {CFG_NAMES.get(c, str(c)): {'launches': v[2], 'ms': round(v[0], 3), 'tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                                                                 'algorithmic_GB': round(v[3] / 1e9, 3), 'algorithmic_GBps': round(v[3] / 1e9 / (v[0] * 1e-3), 0)}
                                       for c, v in sorted(by.items())},
+         # per launch (layer), in execution order: [cfg id, M, N, K, ms, algorithmic TFLOP/s, algorithmic MB, algorithmic GB/s] -- the waste
+         # ratio of a layer is its share of `traffic` over the MB here
+         'launches': [[c, m[0], m[1], m[2], round(t, 4), round(f / (t * 1e-3) / 1e12, 1), round(b / 1e6, 1), round(b / 1e9 / (t * 1e-3), 0)]
+                      for t, f, c, m, b in rec],
+         'algorithmic_bytes_step': int(algo_step),
          'sampled': 'every contraction launch of one UNTIMED step after warm-up, HIP events on the launch stream, trunk on one stream '
                     '(trunk_streams=1) so a launch\'s duration is its own; the timed steps run two frame ranges on concurrent streams',
-         'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_bench_traffic.sh); bytes per launch'}
+         'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_bench_traffic.sh; FETCH_SIZE doubled per '
+                           'MI355X_MICROARCH.md); bytes per launch, averaged over the symbol\'s launches; L2-miss traffic incl. Infinity-Cache hits',
+         'algorithmic_bytes': 'layer-granular: inputs and residual read once, output written once, weights once (mcg_engine_profile_stop)'}
     if precision == 'f16x3':
         r['note'] = ('achieved = ALGORITHMIC FLOP/s; the f16x3 contraction issues three fp16 MFMAs per algorithmic product, so the matrix pipe runs at '
                      f'{round(3 * achieved, 1)} TFLOP/s = {round(3 * achieved / peak, 4)} of the 16-bit MFMA peak')
     if step_bytes:
         r['hbm_step'] = {'bytes': int(step_bytes), 'contraction_launches_covered': covered, 'of': len(rec), 'peak_GBps': PEAK_HBM_GBPS,
+                         'algorithmic_bytes': int(algo_step), 'over_algorithmic': round(step_bytes / algo_step, 3) if algo_step else None,
                          'note': 'divide by ms_per_step for the whole-path HBM rate; stem, RoIAlign and the small decoder kernels are not in it'}
     return r
 
@@ -366,6 +393,104 @@ def single_clip_latency(precisions, dev, T, size, iters=60):
     return res
 
 
+class _OracleEngine:
+    """The CPU oracle behind the engine interface harness._run_windows drives (forward(x, T, img_hw) -> gaze / boxes / scores):
+    the checker of the mae_proxy leg, never the thing measured."""
+
+    def __init__(self, sd):
+        from oracle import mcgaze_oracle as orc
+        self.orc, self.sd, self.device = orc, orc.as_torch(sd), torch.device('cpu')
+
+    def forward(self, x, T, img_hw=None):
+        N, _, H, W = x.shape
+        gaze, boxes, scores = [], [], []
+        for b in range(N // T):
+            hw = [(H, W)] * T if img_hw is None else [tuple(int(v) for v in r) for r in np.asarray(img_hw).reshape(-1, 2)[b * T:(b + 1) * T]]
+            metas = [dict(img_shape=(h, w, 3), ori_shape=(h, w, 3), pad_shape=(H, W, 3), scale_factor=np.ones(4, dtype=np.float32), flip=False) for h, w in hw]
+            det, g = self.orc.forward(self.sd, x[b * T:(b + 1) * T].numpy(), metas, T)
+            gaze.append(torch.stack([g['gaze_score'], g['face_gaze_score'], g['eyes_gaze_score'], g['head_gaze_score']]))
+            boxes.append(det[..., :4]); scores.append(det[..., 4])
+        return dict(gaze=torch.cat(gaze, dim=1), boxes=torch.cat(boxes), scores=torch.cat(scores))
+
+
+def mae_proxy(engines, dev, n_videos, T, frames_per_video=31, src=320, cpu_threads=16, gt_sigma=0.155):
+    """The MAE half of north_star without the dataset (absent here): what a precision mode does to the reference's METRIC.
+    Synthetic videos (smooth frame-dependent uint8 content) -> the config's test pipeline on the device (seeded CenterCrop draws,
+    Resize, Normalize, Pad: mcg_preprocess_frames) -> 7-frame windows with stride 4 -> engine -> overlap merge
+    (tools/test_gaze360_gaze.py:72-206) -> smooth_filter + mean angular error (tools/calculate_mae_gaze360.py:16-29,77-94,136-187).
+    Every engine and the fp32 CPU oracle see the SAME preprocessed frames.  Reported per engine, in degrees:
+      vs_oracle_deg    MAE with the oracle's own smoothed predictions as ground truth (0 for the oracle itself)
+      synthetic_gt_deg MAE against a synthetic ground truth drawn ~10.7 degrees from the oracle's predictions (the README's 10.74)
+      shift_deg        synthetic_gt_deg minus the oracle's -- the quantity north_star bounds by +-0.05
+    Random-init weights: a trained checkpoint's boxes sit on heads and faces inside the frame, these sprawl, so the
+    16-bit engine's figure is an upper bound of unknown slack, not a verdict on the real model."""
+    from PIL import Image
+    from mcgaze_amd import Config, harness, metric, synth
+    from mcgaze_amd.pipeline import DevicePipeline
+    pipe = DevicePipeline(Config.fromfile(os.path.join(ROOT, 'configs', 'mcgaze', 'r50_clip7_gaze360.py')).data.test.pipeline)
+    rs = np.random.RandomState(2024)
+    videos = []
+    for vid in range(n_videos):
+        base = rs.randint(0, 256, (src // 8 + 1, src // 8 + 1, 3)).astype(np.uint8)
+        frames = [np.ascontiguousarray(np.asarray(Image.fromarray(np.roll(base, (i, 2 * i), axis=(0, 1))).resize((src, src), Image.BILINEAR))[..., ::-1])
+                  for i in range(frames_per_video)]
+        img, metas = pipe(frames, device=dev, rng=np.random.RandomState(100 + vid))
+        torch.cuda.synchronize(dev)
+        videos.append(dict(id=vid, frames=img, img_hw=np.array([m['img_shape'][:2] for m in metas], dtype=np.int32)))
+    sd = synth.make_state_dict(0)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(cpu_threads, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    try:
+        ref = harness.run_videos(_OracleEngine(sd), [dict(id=v['id'], frames=v['frames'].cpu(), img_hw=v['img_hw']) for v in videos], clip_len=T, batch_clips=8)
+    finally:
+        torch.set_num_threads(threads)
+    cpu_s = time.perf_counter() - t0
+    gt_rs = np.random.RandomState(7)
+    oracle_gt, synth_gt = dict(annotations=[]), dict(annotations=[])
+    for r in ref:
+        g = metric.smooth_filter(torch.tensor(r['fusion_gazes']))
+        oracle_gt['annotations'].append(dict(gaze=g.tolist()))
+        noisy = g + gt_sigma * torch.from_numpy(gt_rs.standard_normal(tuple(g.shape)).astype(np.float32))
+        synth_gt['annotations'].append(dict(gaze=(noisy / noisy.norm(dim=1, keepdim=True)).tolist()))
+    base = metric.gaze_error(ref, synth_gt, verbose=False)['mae_360']
+    out = {'what': mae_proxy.__doc__.split('Reported per engine')[0].strip().replace('\n    ', ' '),
+           'videos': n_videos, 'frames': n_videos * frames_per_video, 'windows': sum(len(harness.plan_windows(frames_per_video, T)) for _ in videos),
+           'oracle_synthetic_gt_deg': round(base, 4), 'oracle_cpu_seconds': round(cpu_s, 1), 'tolerance_deg': 0.05, 'engines': {}}
+    for name, eng in engines.items():
+        rec = harness.run_videos(eng, videos, clip_len=T, batch_clips=64)
+        torch.cuda.synchronize(dev)
+        vs = metric.gaze_error(rec, oracle_gt, verbose=False)['mae_360']
+        sg = metric.gaze_error(rec, synth_gt, verbose=False)['mae_360']
+        worst = max(float(torch.rad2deg(torch.acos((metric.smooth_filter(torch.tensor(a['fusion_gazes'])) * torch.tensor(b['gaze'])).sum(-1).clamp(-1, 1))).max())
+                    for a, b in zip(rec, oracle_gt['annotations']))
+        out['engines'][name] = {'vs_oracle_deg': round(vs, 5), 'max_frame_vs_oracle_deg': round(worst, 4), 'synthetic_gt_deg': round(sg, 4),
+                                'shift_deg': round(sg - base, 5), 'within_0p05_deg': bool(abs(sg - base) <= 0.05)}
+    return out
+
+
+def timed_leg(leg, steps, warmup, total_per_step, flops_per_clip, world):
+    el = leg.timed(steps, warmup)
+    v = total_per_step * steps / el
+    return el, {'value': round(v, 2), 'unit': 'clips/s', 'steps': steps, 'ms_per_step': round(el / steps * 1e3, 3),
+                'model_tflops': round(v * flops_per_clip / 1e12, 1), 'frac_of_bf16_mfma_peak': round(v * flops_per_clip / 1e12 / (PEAK_BF16_TFLOPS * world), 4)}
+
+
+def verify_ring_neighbour(leg, world, rank, T, size, strong_b=None):
+    """Proof that the exchange really crossed ranks: rank r recomputes clip 0 of rank (r+1) % N -- same seeded generator, its own engine --
+    and compares it BIT FOR BIT with that rank's block of the gathered buffer of the last timed step.  -> 1 if equal else 0."""
+    from mcgaze_amd import synth
+    q = (rank + 1) % world
+    slot = (leg.k - 1) & 1
+    torch.cuda.current_stream(leg.dev).synchronize()
+    g = leg.gathers[slot]
+    theirs = g.rank_views(q) if world > 1 else g.local_views()
+    one = leg.eng.forward(torch.from_numpy(synth.make_clips(3 + q, 1, T, size, size)).to(leg.dev), T)
+    torch.cuda.synchronize(leg.dev)
+    ok = (torch.equal(one['gaze'], theirs['gaze'][:, :T]) and torch.equal(one['boxes'], theirs['boxes'][:T]) and torch.equal(one['scores'], theirs['scores'][:T]))
+    return int(ok)
+
+
 def main():
     a = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -396,72 +521,116 @@ def main():
         B, total_per_step, scaling = a.clips_per_gpu, a.clips_per_gpu * world, 'weak'
     img_np = synth.make_clips(3 + rank, B, T, a.size, a.size)
     img = torch.from_numpy(img_np).to(dev)
-
-    # ------------------------------------------------------------------ headline engine
-    leg = Leg(a, a.precision, dev, world, rank, dist, img, B, T)
-    for _ in range(2):
-        leg.step()
-    leg.drain()
-    torch.cuda.synchronize(dev)
-    roofline = roofline_of(leg.sample_kernels(), a.precision) if a.kernel_events == 'sample' else None
-    elapsed = leg.timed(a.steps, a.warmup)
-    verified = leg.verify()
+    flops_per_clip = {'full': FLOPS_PER_CLIP, 'backbone_fpn': FLOPS_PER_CLIP_TRUNK, 'backbone': FLOPS_PER_CLIP_BACKBONE}[a.workload]
     want_yp = oracle_clip0(img_np, T, a.size) if (rank == 0 and a.workload == 'full') else None
-    head_dev = deviation(leg.outs[0], want_yp, T) if want_yp is not None else None
 
-    # ------------------------------------------------------------------ parity engine, same protocol
-    parity = None
-    if a.parity_engine not in ('none', a.precision) and a.workload == 'full':
+    def run_engine(precision, steps, warmup):
+        """One engine under the product schedule: sampling step, timed region, bitwise verification, deviation from the oracle,
+        the ring-neighbour check of the exchange, and the backbone-only sub-measurement (configs[1]) on the same engine."""
+        leg = Leg(a, precision, dev, world, rank, dist, img, B, T)
+        for _ in range(2):
+            leg.step()
+        leg.drain()
+        torch.cuda.synchronize(dev)
+        roof = roofline_of(leg.sample_kernels(), precision) if a.kernel_events == 'sample' else None
+        el, res = timed_leg(leg, steps, warmup, total_per_step, flops_per_clip, world)
+        res['timed_region_s'] = round(el, 3)
+        res['verified'] = leg.verify()
+        d = deviation(leg.outs[0], want_yp, T) if want_yp is not None else None
+        res['max_abs_dev_yaw_pitch_clip0'] = d
+        res['tolerance'] = PARITY_TOL
+        res['within_tolerance'] = (d is not None and d <= PARITY_TOL) if want_yp is not None else None
+        if dist is not None and a.workload == 'full':
+            ok = torch.tensor([verify_ring_neighbour(leg, world, rank, T, a.size)], dtype=torch.int64, device=dev)
+            dist.all_reduce(ok)
+            res['rccl_ranks_verified'] = int(ok.item())
+        if roof and 'hbm_step' in roof:
+            gbps = roof['hbm_step']['bytes'] / (el / steps) / 1e9
+            roof['hbm_step'].update({'achieved_GBps': round(gbps, 1), 'frac': round(gbps / PEAK_HBM_GBPS, 4)})
+        res['roofline'] = roof
+        back = None
+        if world == 1 and a.backbone_clips > 0 and a.workload == 'full':
+            del leg.runner
+            leg.runner = None
+            bimg = torch.from_numpy(synth.make_clips(11, a.backbone_clips, T, a.size, a.size)).to(dev)
+            bleg = Leg(a, precision, dev, 1, 0, None, bimg, a.backbone_clips, T, workload='backbone', engine=leg.eng)
+            _, back = timed_leg(bleg, max(10, min(steps, 50)), 3, a.backbone_clips, FLOPS_PER_CLIP_BACKBONE, 1)
+            del bleg, bimg
+        return leg, res, back
+
+    WHAT = {'f16x3': 'f32 activations, weights split-packed into fp16 high / low halves, three fp16 MFMAs per product, f32 accumulate (include/mcgaze_hip.h MCG_F16X3); the library default',
+            'bf16': 'bf16 activations and weights, bf16 MFMA, f32 accumulate; f32 LayerNorm / softmax / boxes (MCG_BF16); explicit opt-in',
+            'fp32': 'f32 storage and f32 MFMA (MCG_F32)'}
+    leg, head, head_back = run_engine(a.precision, a.steps, a.warmup)
+    engines_for_mae = {a.precision: leg.eng}
+    second, second_back = None, None
+    if a.second_engine not in ('none', a.precision) and a.workload == 'full':
         del leg.runner
         leg.runner = None
-        pleg = Leg(a, a.parity_engine, dev, world, rank, dist, img, B, T)
-        for _ in range(2):
-            pleg.step()
-        pleg.drain()
-        torch.cuda.synchronize(dev)
-        proof = roofline_of(pleg.sample_kernels(), a.parity_engine) if a.kernel_events == 'sample' else None
-        psteps = a.parity_steps or max(10, a.steps // 4)
-        pel = pleg.timed(psteps, max(2, a.warmup // 3))
-        pver = pleg.verify()
-        pval = total_per_step * psteps / pel
-        parity = {'dtype': a.parity_engine, 'value': round(pval, 2), 'unit': 'clips/s', 'steps': psteps, 'ms_per_step': round(pel / psteps * 1e3, 3),
-                  'verified': pver, 'model_tflops': round(pval * FLOPS_PER_CLIP / 1e12, 1),
-                  'max_abs_dev_yaw_pitch_clip0': deviation(pleg.outs[0], want_yp, T) if want_yp is not None else None,
-                  'tolerance': PARITY_TOL, 'oracle': 'oracle/mcgaze_oracle.py (fp32 CPU restatement pinned to the reference goldens) on clip 0 of this batch',
-                  'what': 'f32 activations, weights split-packed into fp16 high / low halves, three fp16 MFMAs per product, f32 accumulate (include/mcgaze_hip.h MCG_F16X3)'
-                          if a.parity_engine == 'f16x3' else 'f32 storage and f32 MFMA',
-                  'roofline': proof}
-        del pleg
+        sleg, second, second_back = run_engine(a.second_engine, a.second_steps or a.steps, max(2, a.warmup))
+        second = dict({'dtype': a.second_engine, 'what': WHAT[a.second_engine],
+                       'oracle': 'oracle/mcgaze_oracle.py (fp32 CPU restatement pinned to the reference goldens) on clip 0 of this batch'}, **second)
+        engines_for_mae[a.second_engine] = sleg.eng
+        del sleg.runner
+        sleg.runner = None
+
+    # ------------------------------------------------------------------ N > 1: the fixed-batch (strong scaling) figure in the same line
+    strong = None
+    if world > 1 and a.strong_clips > 0 and a.global_clips == 0 and a.workload == 'full' and a.strong_clips % world == 0:
+        Bs = a.strong_clips // world
+        if Bs == B:
+            strong = {'global_clips': a.strong_clips, 'clips_per_gpu': Bs, 'value': head['value'], 'ms_per_step': head['ms_per_step'],
+                      'note': 'identical to the headline configuration at this N (512 / N = clips_per_gpu)'}
+        else:
+            simg = torch.from_numpy(synth.make_clips(3 + rank, Bs, T, a.size, a.size)).to(dev)
+            stl = Leg(a, a.precision, dev, world, rank, dist, simg, Bs, T, engine=leg.eng)
+            _, strong = timed_leg(stl, max(5, min(a.steps, 10)), 2, a.strong_clips, FLOPS_PER_CLIP, world)
+            strong.update({'global_clips': a.strong_clips, 'clips_per_gpu': Bs, 'scaling': 'strong'})
+            del stl.runner, stl, simg
 
     if rank == 0:
-        total_clips = total_per_step * a.steps
-        flops_per_clip = {'full': FLOPS_PER_CLIP, 'backbone_fpn': FLOPS_PER_CLIP_TRUNK, 'backbone': FLOPS_PER_CLIP_BACKBONE}[a.workload]
-        value = total_clips / elapsed
-        if roofline and 'hbm_step' in roofline:
-            gbps = roofline['hbm_step']['bytes'] / (elapsed / a.steps) / 1e9
-            roofline['hbm_step'].update({'achieved_GBps': round(gbps, 1), 'frac': round(gbps / PEAK_HBM_GBPS, 4)})
         line = {
-            'metric': 'clips/sec (7x3x224x224)', 'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': a.steps,
-            'warmup': a.warmup, 'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': scaling,
+            'metric': 'clips/sec (7x3x224x224)', 'value': head['value'], 'unit': 'clips/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic (seeded N(0,1) clips, random-init weights, resident in HBM)',
             'config': {'workload': {'full': 'full multiclue_gaze_r50 forward (R-50 + FPN + 4 decoder stages + gaze head), ', 'backbone_fpn': 'R-50 backbone + FPN only (BASELINE.json configs[1]), ', 'backbone': 'R-50 backbone only, C2..C5 (BASELINE.json configs[1]; mcg_bench_backbone_forward), '}[a.workload] +
                                    f'{B} clips/GPU x {T} frames x 3x{a.size}x{a.size}, {total_per_step} clips/step',
                        'clips_per_gpu': B, 'clip_length': T, 'global_clips': total_per_step, 'chunk_frames': a.chunk_frames,
+                       'engine': WHAT[a.precision],
                        'parallelism': f'dp{world} (clips sharded by rank, one fused all_gather of results per step)' if world > 1 else 'single GPU',
                        'batch_pipeline': 'decoder(step k) overlaps trunk(step k+1) on a second HIP stream; the loop submits from the trunk stream; all K batches complete inside the timed region' if (a.pipeline and a.workload == 'full') else 'none (serial)',
                        'trunk_streams': a.trunk_streams},
-            'timed_region_s': round(elapsed, 3),
-            'verified': verified,
+            'world_size': dist.get_world_size() if dist is not None else 1,
+            'timed_region_s': head['timed_region_s'],
+            'verified': head['verified'],
             'verified_how': 'after the timed loop the batch is re-run strictly serially (trunk_streams=1, no batch pipeline, one stream); gaze / boxes / scores of both pipeline slots must equal it bit for bit',
-            'max_abs_dev_yaw_pitch_clip0': head_dev,
-            'model_tflops': round(value * flops_per_clip / 1e12, 1),
-            'frac_of_bf16_mfma_peak': round(value * flops_per_clip / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
-            'roofline': roofline,
-            'parity_engine': parity,
+            'max_abs_dev_yaw_pitch_clip0': head['max_abs_dev_yaw_pitch_clip0'], 'tolerance': PARITY_TOL, 'within_tolerance': head['within_tolerance'],
+            'oracle': 'oracle/mcgaze_oracle.py (fp32 CPU restatement pinned to the reference goldens) on clip 0 of this batch',
+            'model_tflops': head['model_tflops'],
+            'frac_of_bf16_mfma_peak': head['frac_of_bf16_mfma_peak'],
+            'roofline': head['roofline'],
         }
+        if 'rccl_ranks_verified' in head:
+            line['rccl_ranks_verified'] = head['rccl_ranks_verified']
+            line['rccl_verified_how'] = verify_ring_neighbour.__doc__.split('->')[0].strip().replace('\n    ', ' ')
+        if strong is not None:
+            line['strong_scaling'] = strong
+        if second is not None:
+            line['throughput_engine' if a.second_engine == 'bf16' else 'second_engine'] = second
+        if head_back is not None:
+            line['backbone'] = {'what': f'BASELINE.json configs[1]: R-50 backbone only (stem + layer1..4, C2..C5; mcg_bench_backbone_forward), {a.backbone_clips} clips x {T} frames x 3x{a.size}x{a.size}, '
+                                        f'{FLOPS_PER_CLIP_BACKBONE / 1e9:.2f} GFLOP per clip, two concurrent frame ranges', a.precision: head_back}
+            if second_back is not None:
+                line['backbone'][a.second_engine] = second_back
+        if world == 1 and a.mae_videos > 0 and a.workload == 'full':
+            from mcgaze_amd.engine import HipEngine
+            if 'fp32' not in engines_for_mae:
+                engines_for_mae['fp32'] = HipEngine(synth.make_state_dict(0), precision='fp32', device=dev)
+            line['mae_proxy'] = mae_proxy(engines_for_mae, dev, a.mae_videos, T)
+        engines_for_mae.clear()
         if world == 1 and a.latency and a.workload == 'full':
             del leg
-            line['latency_single_clip'] = single_clip_latency([p for p in dict.fromkeys([a.precision, a.parity_engine]) if p != 'none'], dev, T, a.size)
+            line['latency_single_clip'] = single_clip_latency([p for p in dict.fromkeys([a.precision, a.second_engine]) if p != 'none'], dev, T, a.size)
         if world == 1 and a.cpu_seconds > 0:
             line['cpu_baseline'] = cpu_baseline(a.cpu_seconds, T, a.size)
             if 'latency_single_clip' in line:

@@ -29,13 +29,15 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 7
+#define MCG_ABI_VERSION 8
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
 /* MCG_F16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
  * f32 storage); only the contraction differs: every conv / linear weight matrix is handed over SPLIT-PACKED -- per 8 consecutive
  * K elements a 16-byte chunk of fp16 HIGH parts followed by a 16-byte chunk of fp16 LOW parts (w = hi + lo, lo = f16(w - hi):
- * 22 significant bits; 4 bytes per element like f32) -- the f32 activations are split the same way in registers (round toward zero,
+ * 22 significant bits for |w| >= 0.125; below that the low half is an fp16 SUBNORMAL with an absolute error of 2^-25, so a weight of
+ * magnitude 1e-2 keeps ~18 bits and one of 1e-3 ~15 -- tests/test_gpu_kernels.py::test_f16x3_small_weights measures it; 4 bytes per
+ * element like f32) -- the f32 activations are split the same way in registers (round toward zero,
  * x - hi exact), and each product runs as three fp16 MFMAs (lo.hi + hi.lo + hi.hi) with f32 accumulation.  Operands beyond
  * +-65504 saturate per half (the reference's activations are orders of magnitude below); parts below 6e-8 flush to zero.
  * Measured: 1e-5 rad on (yaw, pitch) against the reference (north_star: 1e-3), within a factor 2 of the MCG_F32 engine. */
@@ -194,6 +196,28 @@ typedef struct {
 } mcg_model_weights;
 
 typedef struct mcg_engine mcg_engine;
+/* Threading and streams (what a host that drives the library from several threads may rely on)
+ *   - The stand-alone operators (mcg_conv2d ... mcg_gaze_head, mcg_preprocess_frames) keep no state: any thread, any stream.
+ *     mcg_last_error() is thread-local.
+ *   - An ENGINE runs ONE forward at a time.  mcg_backbone_fpn_forward / mcg_clip_forward / mcg_bench_backbone_forward /
+ *     mcg_engine_set_option / mcg_engine_profile_* take the engine's mutex for the duration of the ENQUEUE (they never wait for
+ *     the GPU): two host threads calling into the same engine are serialised silently, in lock order, and both calls are
+ *     correct -- but they share the engine's fork / join events and the caller-provided workspace, so they must not pass the
+ *     same workspace unless they also enqueue on the same stream.  mcg_decoder_forward touches no engine state beyond the
+ *     (immutable) weight tables and does not take the mutex: it may run on another thread / stream beside the trunk of the
+ *     next batch (mcgaze_amd/engine.py: PipelinedRunner) as long as its workspace and pyramid are its own.
+ *     For concurrent forwards on one device use one engine per thread (weights may be shared: the engine copies only the
+ *     tables); tests/test_gpu_forward.py::test_two_threads_two_engines_one_device asserts bit-identical results.
+ *   - Streams: every call is ordered on the caller's stream `s` -- work queued on `s` before the call is visible to it, work
+ *     queued on `s` after the call sees its results.  With trunk_streams > 1 the trunk forks frame ranges onto side streams
+ *     and joins them back into `s` with events before returning, so this still holds; the side streams come from a
+ *     per-DEVICE pool of 8 non-blocking streams created once per process and shared by every engine on that device (streams
+ *     created later in a process's life serialise against earlier ones on this runtime), chosen per caller stream by a
+ *     one-off concurrency probe (a ~1 ms host wait on the first call that sees a new caller stream; never on the hot path
+ *     afterwards).  Two engines driven concurrently on one device therefore share side streams: results are unaffected,
+ *     their trunks' frame ranges may serialise against each other.
+ *   - The library reads no environment variable and never synchronises the device on the hot path; mcg_engine_profile_stop
+ *     and the first-call probe are the only host waits. */
 /* The engine copies the weight TABLES (not the weights); device buffers stay caller-owned. */
 int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, mcg_dtype dt);
 void mcg_engine_destroy(mcg_engine* e);
@@ -248,10 +272,11 @@ int mcg_preprocess_frames(mcg_stream stream, const mcg_frame_desc* frames_dev, i
 
 /* ---------------------------------------------------------------- measurement aids (bench.py)
  * While armed, every launch of the contraction kernel made by THIS engine is bracketed by a hipEvent pair on its launch stream.
- * mcg_engine_profile_stop synchronises, returns per-launch duration (ms), algorithmic FLOPs, tile-configuration id (bench.py
- * CFG_NAMES) and the GEMM shape (M, N, K) of every recorded launch (any output array may be NULL), and disarms. */
+ * mcg_engine_profile_stop synchronises, returns per-launch duration (ms), algorithmic FLOPs, algorithmic HBM bytes (inputs and
+ * residual read once, output written once, weights once -- what a layer-granular schedule cannot go below), tile-configuration id
+ * (bench.py CFG_NAMES) and the GEMM shape (M, N, K) of every recorded launch (any output array may be NULL), and disarms. */
 int mcg_engine_profile_start(mcg_engine* e, int capacity);
-int mcg_engine_profile_stop(mcg_engine* e, int* count, float* ms, double* flops, int* cfg, int* shape_mnk, int capacity);
+int mcg_engine_profile_stop(mcg_engine* e, int* count, float* ms, double* flops, double* algo_bytes, int* cfg, int* shape_mnk, int capacity);
 /* BASELINE.json configs[1] "R-50 backbone-only": stem + layer1..4 (C2..C5 stay in the workspace), no FPN.  Not a product entry
  * point; ws >= mcg_trunk_workspace_bytes(e, num_frames, H, W, 0). */
 int mcg_bench_backbone_forward(mcg_engine* e, mcg_stream s, const float* img, int num_frames, int H, int W, void* ws, size_t ws_bytes);

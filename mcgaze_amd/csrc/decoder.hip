@@ -453,7 +453,7 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
     PwSingleParams pp;
     memset(&pp, 0, sizeof(pp));
     pp.a = w.x2; pp.wf = W[MCG_SW_DYN_WF]; pp.bias = f32w[MCG_SW_DYN_B]; pp.y = w.params; pp.M = R; pp.Ho = 1; pp.Wo = 1;
-    ProfRec* rec = prof_begin(ctx, s, 62, R, 32768, 256, 2.0 * R * 32768 * 256);
+    ProfRec* rec = prof_begin(ctx, s, 62, R, 32768, 256, 2.0 * R * 32768 * 256, 2.0 * ((double)R * (256 + 32768) + 32768.0 * 256));
     const int rc = launch_pw_dyn(s, pp);
     prof_end(rec, s);
     if (rc) { mcg_set_error("pw_single (dynamic_layer) launch failed"); return MCG_ERR_HIP; }

@@ -198,8 +198,15 @@ extern "C" int mcg_engine_profile_start(mcg_engine* e, int capacity) {
   if (e->prof.recs) { mcg_set_error("mcg_engine_profile_start: already armed"); return MCG_ERR_ARG; }
   MCG_CHECK_ARG(capacity > 0 && capacity <= (1 << 20), "mcg_engine_profile_start: bad capacity %d", capacity);
   e->prof.recs = new ProfRec[capacity];
+  for (int i = 0; i < capacity; ++i) { e->prof.recs[i].a = nullptr; e->prof.recs[i].b = nullptr; }
   for (int i = 0; i < capacity; ++i) {
     if (hipEventCreate(&e->prof.recs[i].a) != hipSuccess || hipEventCreate(&e->prof.recs[i].b) != hipSuccess) {
+      for (int j = 0; j <= i; ++j) {   // undo: the engine must stay re-armable
+        if (e->prof.recs[j].a) (void)hipEventDestroy(e->prof.recs[j].a);
+        if (e->prof.recs[j].b) (void)hipEventDestroy(e->prof.recs[j].b);
+      }
+      delete[] e->prof.recs;
+      e->prof = Prof();
       mcg_set_error("mcg_engine_profile_start: hipEventCreate failed");
       return MCG_ERR_HIP;
     }
@@ -208,7 +215,7 @@ extern "C" int mcg_engine_profile_start(mcg_engine* e, int capacity) {
   e->ctx.prof = &e->prof;
   return MCG_OK;
 }
-extern "C" int mcg_engine_profile_stop(mcg_engine* e, int* count, float* ms, double* flops, int* cfg, int* shape, int capacity) {
+extern "C" int mcg_engine_profile_stop(mcg_engine* e, int* count, float* ms, double* flops, double* bytes, int* cfg, int* shape, int capacity) {
   MCG_CHECK_ARG(e, "mcg_engine_profile_stop: null engine");
   std::lock_guard<std::mutex> lock(e->mu);
   if (!e->prof.recs) { mcg_set_error("mcg_engine_profile_stop: not armed"); return MCG_ERR_ARG; }
@@ -221,6 +228,7 @@ extern "C" int mcg_engine_profile_stop(mcg_engine* e, int* count, float* ms, dou
     if (i < capacity) {
       if (ms) ms[i] = t;
       if (flops) flops[i] = r.flops;
+      if (bytes) bytes[i] = r.bytes;
       if (cfg) cfg[i] = r.cfg;
       if (shape) { shape[3 * i] = r.shape[0]; shape[3 * i + 1] = r.shape[1]; shape[3 * i + 2] = r.shape[2]; }
     }
@@ -288,7 +296,9 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
     pp.a = x; pp.res = res; pp.wf = cw.wf; pp.bias = cw.bias; pp.y = y;
     pp.M = (int)M; pp.relu = relu; pp.Ho = h; pp.Wo = w;
     if (rm == MCG_RES_UPSAMPLE_ADD) { pp.Hr = hr; pp.Wr = wr; pp.rscale_h = (float)hr / (float)h; pp.rscale_w = (float)wr / (float)w; }
-    ProfRec* rec = prof_begin(e->ctx, s, 61, pp.M, cw.cout, cw.cin, 2.0 * M * cw.cin * cw.cout);
+    const double res_rows = rm == MCG_RES_NONE ? 0.0 : (rm == MCG_RES_ADD ? (double)M : (double)n * hr * wr);
+    ProfRec* rec = prof_begin(e->ctx, s, 61, pp.M, cw.cout, cw.cin, 2.0 * M * cw.cin * cw.cout,
+                              2.0 * ((double)M * (cw.cin + cw.cout) + res_rows * cw.cout + (double)cw.cin * cw.cout));
     const int prc = launch_pw_single(s, pp, cw.cin, cw.cout, rm == MCG_RES_NONE ? 0 : (rm == MCG_RES_ADD ? 1 : 2));
     prof_end(rec, s);
     if (prc) { mcg_set_error("pw_single launch failed"); return MCG_ERR_HIP; }
@@ -333,7 +343,8 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
         pp.w1f = c1n->wf; pp.b1 = c1n->bias; pp.z = t.o1;
         pp.M = n * ho * wo; pp.C = c3.cout; pp.C2 = c1n->cout; pp.Ho = ho; pp.Wo = wo;
         // cfg 60: both contractions of the pair count (2 M (K C + C C2))
-        ProfRec* rec = prof_begin(e->ctx, s, 60, pp.M, pp.C + pp.C2, pp.K1 + pp.K2, 2.0 * pp.M * ((double)(pp.K1 + pp.K2) * pp.C + (double)pp.C * pp.C2));
+        ProfRec* rec = prof_begin(e->ctx, s, 60, pp.M, pp.C + pp.C2, pp.K1 + pp.K2, 2.0 * pp.M * ((double)(pp.K1 + pp.K2) * pp.C + (double)pp.C * pp.C2),
+                                  2.0 * ((double)pp.M * (pp.K1 + pp.K2 + (has_ds ? 0 : pp.C) + pp.C + pp.C2) + (double)(pp.K1 + pp.K2) * pp.C + (double)pp.C * pp.C2));
         const int prc = launch_pw_pair(s, pp);
         prof_end(rec, s);
         if (prc) { mcg_set_error("pw_pair launch failed"); return MCG_ERR_HIP; }

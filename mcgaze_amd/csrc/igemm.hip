@@ -38,13 +38,14 @@ extern "C" int mcg_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int
 // Per-launch profiling of the contraction kernel (bench.py's roofline line): when the context carries an armed Prof, every
 // contraction launch is bracketed by a hipEvent pair on the launch stream and tagged with its algorithmic FLOPs
 // (2*M*Cout*K, true K for the zero-padded stem) and tile configuration.  The records belong to the engine (engine.hip).
-ProfRec* prof_begin(const McgCtx& ctx, hipStream_t s, int cfg, int M, int N, int K, double flops) {
+ProfRec* prof_begin(const McgCtx& ctx, hipStream_t s, int cfg, int M, int N, int K, double flops, double bytes) {
   Prof* pr = ctx.prof;
   if (!pr || pr->n >= pr->cap) return nullptr;
   ProfRec* rec = &pr->recs[pr->n++];
   rec->cfg = cfg;
   rec->shape[0] = M; rec->shape[1] = N; rec->shape[2] = K;
   rec->flops = flops;
+  rec->bytes = bytes;
   (void)hipEventRecord(rec->a, s);
   return rec;
 }
@@ -55,6 +56,19 @@ static double algo_flops(const IgemmParams& p, int groups) {
   return 2.0 * p.M * p.Cout * (p.algo_k > 0 ? (double)p.algo_k : (double)p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0)) * groups;
 }
 static int gemm_k(const IgemmParams& p) { return p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0); }
+// Algorithmic HBM bytes of one launch (layer-granular): every input pixel the taps touch read ONCE (a 1x1 /
+// stride-s conv needs only the sampled pixels; a KxK conv the whole map), the second source and the residual rows once, the output
+// written once, the weights once.  es = bytes per activation element; split-K slabs count as f32 outputs.
+static double algo_bytes(const IgemmParams& p, int groups, int es) {
+  const double frames = (double)p.M / ((double)p.Ho * p.Wo);
+  const double in_px = (p.KH == 1 && p.KW == 1) ? (double)p.M : frames * p.H * p.W;
+  double b = in_px * p.Cin * es + (p.x2 ? (double)p.M * p.Cin2 * es : 0.0);
+  b += p.splitk > 1 ? (double)p.splitk * p.M * p.Cout * 4 : (double)p.M * p.Cout * es;
+  if (p.res_mode == MCG_RES_ADD) b += (double)p.M * p.Cout * es;
+  if (p.res_mode == MCG_RES_UPSAMPLE_ADD) b += frames * p.Hr * p.Wr * p.Cout * es;
+  b += (double)p.Cout * gemm_k(p) * es;
+  return b * groups;
+}
 
 template <typename T, int BM, int BN, int BKB, int WM, int WN>
 static void launch_cfg(hipStream_t s, const IgemmParams& p, int groups) {
@@ -120,7 +134,7 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups, const M
   }
   // cfg ids (bench.py CFG_NAMES): 0..3 f32 register-staged, 4..7 bf16 register-staged, 15 = 256x64 DMA, 16 + tile = DMA tiles
   const int cfg = dma ? (p.Cout <= 64 ? 15 : 16 + tile) : (ES == 2 ? 4 : 0) + (p.Cout <= 64 ? 0 : 2) + (wide ? 1 : 0);
-  ProfRec* rec = prof_begin(ctx, s, cfg, p.M, p.Cout * groups, gemm_k(p), algo_flops(p, groups));
+  ProfRec* rec = prof_begin(ctx, s, cfg, p.M, p.Cout * groups, gemm_k(p), algo_flops(p, groups), algo_bytes(p, groups, ES));
   if (dma) {
     if (p.Cout <= 64) {  // 256x64 tile, 4 waves, 2 stages; the register-capped variant (4 workgroups/CU) pays for long-K (3x3) layers
       if ((long long)p.KH * p.KW * p.Cin >= 512) launch_dma<T, 256, 64, 64, 4, 1, 2, 4>(s, p, groups);
@@ -157,7 +171,7 @@ static int launch_x3(hipStream_t s, const IgemmParams& p, int groups, const McgC
   const long long t256 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
   int tile = p.Cout <= 64 ? 52 : (p.Cout % 256 == 0 && t256 >= 200 ? 50 : 51);
   if (ctx.tile >= 50 && ctx.tile <= 51 && p.Cout > 64) tile = ctx.tile;
-  ProfRec* rec = prof_begin(ctx, s, tile, p.M, p.Cout * groups, gemm_k(p), algo_flops(p, groups));
+  ProfRec* rec = prof_begin(ctx, s, tile, p.M, p.Cout * groups, gemm_k(p), algo_flops(p, groups), algo_bytes(p, groups, 4));
   if (tile == 50) launch_dma<float, 256, 256, 128, 4, 2, 2, 2, 1>(s, p, groups);
   else if (tile == 51) launch_dma<float, 128, 128, 128, 2, 2, 2, 2, 1>(s, p, groups);
   else launch_dma<float, 256, 64, 128, 4, 1, 2, 2, 1>(s, p, groups);
@@ -240,7 +254,7 @@ int conv2d_ctx(hipStream_t s, mcg_dtype dt, const mcg_conv_desc* d, const McgCtx
   if (dt == MCG_BF16 && d->bias && ctx.c64 && !ctx.staged && ctx.tile < 0 &&
       conv3x3_c64_applicable(d->KH, d->KW, d->stride, d->pad, d->Cin, d->Cout, p.res_mode != MCG_RES_NONE, d->x2 != nullptr)) {
     // layer1's conv2: window staged once, nine taps by address (conv3x3_c64.hpp); bit-identical to the generic kernel
-    ProfRec* rec = prof_begin(ctx, s, 40, p.M, 64, 576, 2.0 * p.M * 64 * 576);
+    ProfRec* rec = prof_begin(ctx, s, 40, p.M, 64, 576, 2.0 * p.M * 64 * 576, algo_bytes(p, 1, 2));
     const int rc = launch_conv3x3_c64(s, d->x, d->w, d->bias, d->y, d->N, d->H, d->W, d->relu);
     prof_end(rec, s);
     if (rc) { mcg_set_error("conv3x3_c64 launch failed"); return MCG_ERR_HIP; }

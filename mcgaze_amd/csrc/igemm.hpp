@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // point down to the launchers -- the library reads no environment variable and keeps no mutable process-global state.
 // An engine owns one (mcg_engine_set_option / mcg_engine_profile_start); the stand-alone operator entry points build one from
 // their `tile` / `flags` arguments (include/mcgaze_hip.h, MCG_FLAG_*).
-struct ProfRec { hipEvent_t a, b; double flops; int cfg; int shape[3]; };
+struct ProfRec { hipEvent_t a, b; double flops; double bytes; int cfg; int shape[3]; };  // bytes: ALGORITHMIC HBM bytes of the launch (inputs + residual read once, output written once, weights once)
 struct Prof { ProfRec* recs = nullptr; int cap = 0, n = 0; };
 struct McgCtx {
   int tile = -1;             // forced tile id of igemm_dma_kernel for Cout > 64 (bf16), -1 = heuristic (launch_typed)
@@ -284,7 +284,7 @@ struct McgCtx {
 };
 
 // Profiling hooks (igemm.hip): bracket one launch with the context's event pair, tagged with a configuration id and its work.
-ProfRec* prof_begin(const McgCtx& ctx, hipStream_t s, int cfg, int M, int N, int K, double flops);
+ProfRec* prof_begin(const McgCtx& ctx, hipStream_t s, int cfg, int M, int N, int K, double flops, double bytes = 0.0);
 void prof_end(ProfRec* rec, hipStream_t s);
 
 // Host-side launcher (igemm.hip).  Picks the tile shape from Cout / M.

@@ -201,11 +201,12 @@ class HipEngine:
         L.check(self.lib.mcg_engine_profile_start(self._handle, capacity), 'mcg_engine_profile_start')
 
     def profile_stop(self, capacity=4096):
-        """-> list of (ms, algorithmic flops, cfg id, (M, N, K)) per contraction launch recorded since profile_start."""
+        """-> list of (ms, algorithmic flops, cfg id, (M, N, K), algorithmic HBM bytes) per contraction launch recorded since profile_start."""
         cnt = C.c_int()
-        ms = (C.c_float * capacity)(); fl = (C.c_double * capacity)(); cf = (C.c_int * capacity)(); sh = (C.c_int * (3 * capacity))()
-        L.check(self.lib.mcg_engine_profile_stop(self._handle, C.byref(cnt), ms, fl, cf, sh, capacity), 'mcg_engine_profile_stop')
-        return [(ms[i], fl[i], cf[i], (sh[3 * i], sh[3 * i + 1], sh[3 * i + 2])) for i in range(cnt.value)]
+        ms = (C.c_float * capacity)(); fl = (C.c_double * capacity)(); by = (C.c_double * capacity)()
+        cf = (C.c_int * capacity)(); sh = (C.c_int * (3 * capacity))()
+        L.check(self.lib.mcg_engine_profile_stop(self._handle, C.byref(cnt), ms, fl, by, cf, sh, capacity), 'mcg_engine_profile_stop')
+        return [(ms[i], fl[i], cf[i], (sh[3 * i], sh[3 * i + 1], sh[3 * i + 2]), by[i]) for i in range(cnt.value)]
 
     def backbone_only(self, img):
         """BASELINE.json configs[1] measurement: the trunk up to C5 (mcg_bench_backbone_forward); returns nothing."""
@@ -366,7 +367,10 @@ class PipelinedRunner:
         e, lib, slot = self.e, self.e.lib, self.k & 1
         e._check_img(img)
         img_hw = e.img_hw_tensor(img_hw, self.N)
-        self._hw_keep[slot] = img_hw            # stays alive until the slot's decoder has run
+        if img_hw is not None:
+            img_hw.record_stream(self.sb)       # allocated on the caller's stream, read by the decoder on sb: the caching allocator must
+                                                # not hand the block out again before that read has happened
+        self._hw_keep[slot] = img_hw
         cur = torch.cuda.current_stream(e.device)
         self.sa.wait_stream(cur)                       # input produced on the caller's stream
         if self.used[slot]:

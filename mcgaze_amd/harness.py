@@ -135,14 +135,16 @@ def _run_windows(engine, ids, plans, get_window, batch_clips, person_threshold):
 def run_videos(engine, videos, clip_len=7, stride=4, batch_clips=64, scale_factor=None, person_threshold=0.5):
     """Push whole videos through the HIP engine.
 
-    videos: list of dict(id=…, frames=Tensor[L,3,H,W] f32 already preprocessed (normalised, padded to /32)).
+    videos: list of dict(id=…, frames=Tensor[L,3,H,W] f32 already preprocessed (normalised, padded to /32)[, img_hw=[L,2] int: the
+    per-frame img_shape inside the padded frame -- all videos or none]).
     scale_factor (4 floats) divides the boxes like rescale=True does (multiclue_gaze_roi_head.py:360-363)."""
     plans = [plan_windows(v['frames'].shape[0], clip_len, stride) for v in videos]
 
     def get_window(vi, wi):
         a, b, _ = plans[vi][wi]
         sc = None if scale_factor is None else torch.as_tensor(scale_factor, dtype=torch.float32).expand(b - a, 4)
-        return videos[vi]['frames'][a:b], None, sc
+        hw = videos[vi].get('img_hw')
+        return videos[vi]['frames'][a:b], (None if hw is None else hw[a:b]), sc
 
     return _run_windows(engine, [v['id'] for v in videos], plans, get_window, batch_clips, person_threshold)
 
@@ -168,7 +170,7 @@ def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_cli
     pos = {vw: i for i, vw in enumerate(order)}
     lookahead = 2 * batch_clips if lookahead is None else lookahead
     group = max(1, min(batch_clips, 32))                                    # windows staged per preprocessing call
-    cache = FrameCache(workers, capacity=(lookahead + group + 2) * clip_len)
+    cache = FrameCache(workers, capacity=((lookahead if workers > 0 else 0) + group + 2) * clip_len)   # in-line decoding never runs ahead: only the staged group (and the 3-frame overlap) is worth keeping
     state = dict(ahead=0)
 
     def names_of(vi, wi):

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('MCGAZE_LIB') or os.path.join(_HERE, 'libmcgaze_hip.so
 
 MCG_OK = 0
 MCG_F32, MCG_BF16, MCG_F16X3 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 RES_NONE, RES_ADD, RES_UPSAMPLE_ADD = 0, 1, 2
 FLAG_STAGED_GEMM, FLAG_NO_SPECIALISED = 1, 2
 
@@ -106,7 +106,7 @@ def load():
     lib.mcg_preprocess_frames.argtypes = [vp, vp, i, vp, i, i, C.POINTER(C.c_float), C.POINTER(C.c_float), i]
     lib.mcg_engine_set_option.argtypes = [vp, C.c_char_p, i]
     lib.mcg_engine_profile_start.argtypes = [vp, i]
-    lib.mcg_engine_profile_stop.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(i), C.POINTER(i), i]
+    lib.mcg_engine_profile_stop.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i), C.POINTER(i), i]
     lib.mcg_bench_backbone_forward.argtypes = [vp, vp, vp, i, i, i, vp, sz]
     for name in EXPORTS:
         fn = getattr(lib, name)

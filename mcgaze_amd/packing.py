@@ -63,7 +63,8 @@ def frag_major(w):
 def split_pack(w):
     """f32 [..., K] -> fp16 [..., 2K], the weight operand of the MCG_F16X3 contraction (include/mcgaze_hip.h): per 8 consecutive
     K elements a 16-byte chunk of fp16 high parts, then a 16-byte chunk of fp16 low parts; hi = f16(w), lo = f16(w - hi), so
-    hi + lo = w to 2^-22 relative (values beyond +-65504 saturate per half; low parts below 6e-8 vanish).  4 bytes per element,
+    hi + lo = w to 2^-22 relative for |w| >= 0.125; a smaller weight has its low half in fp16's subnormal range (absolute error
+    2^-25: |w| = 1e-2 keeps ~18 bits, 1e-3 ~15; values beyond +-65504 saturate per half; low parts below 3e-8 vanish).  4 bytes per element,
     like the f32 matrix it replaces."""
     w = w.float()
     K = w.shape[-1]

@@ -32,7 +32,8 @@ def stage_report(eng, prec, sd, img, metas, T, stages):
     """stages: the oracle's per-stage outputs (orc.forward(..., collect=[])).  Returns dict(
     teacher_forced = [obj error of scale per stage, engine stage fed with the ORACLE's inputs],
     free_running   = [(level flips, boxes with a sample-validity flip, obj error of scale, max box |d| px) per stage],
-    discontinuity  = whether the engine's own chain crossed a level / validity boundary the oracle's did not)."""
+    discontinuity  = whether the engine's own chain crossed a level / validity boundary the oracle's did not,
+    crossed_boxes  = bool [R]: the boxes (row = frame * 3 + clue) that did, in any stage)."""
     split = prec == 'f16x3'
     pyr = eng.backbone_fpn(torch.from_numpy(np.ascontiguousarray(img)).to(eng.device))
     hs, ws = [p.shape[1] for p in pyr], [p.shape[2] for p in pyr]
@@ -47,6 +48,7 @@ def stage_report(eng, prec, sd, img, metas, T, stages):
         tf.append(float((o.float().cpu() - want).abs().max() / want.abs().max()))
         bin_, oin = stages[s]['boxes'], stages[s]['obj']
     b, o, ref_in = boxes0.to(dev).contiguous(), obj0.to(dt).to(dev).contiguous(), boxes0
+    crossed = np.zeros(boxes0.reshape(-1, 4).shape[0], dtype=bool)   # per box: a level or sample-validity flip in ANY stage
     for s in range(4):
         roi, lv = E.roi_align(pyr, b)
         ref_lv = orc.map_roi_levels(ref_in.reshape(-1, 4))
@@ -54,11 +56,12 @@ def stage_report(eng, prec, sd, img, metas, T, stages):
         same_lv = (lv.cpu().long() == ref_lv).numpy()
         vf = (sample_validity(b.cpu(), lv.cpu(), hs, ws) != sample_validity(ref_in, ref_lv, hs, ws)).any(axis=1)
         vflips = int((vf & same_lv).sum())
+        crossed |= (~same_lv) | vf
         o, b, _ = E.stage_forward(eng.weights.stages[s], roi, o, b, T, split=split)
         want = stages[s]['obj']
         fr.append((flips, vflips, float((o.float().cpu() - want).abs().max() / want.abs().max()), float((b.cpu() - stages[s]['boxes']).abs().max())))
         ref_in = stages[s]['boxes']
-    return dict(teacher_forced=tf, free_running=fr, discontinuity=any(a or v for a, v, _, _ in fr))
+    return dict(teacher_forced=tf, free_running=fr, discontinuity=any(a or v for a, v, _, _ in fr), crossed_boxes=crossed)
 
 
 def describe(rep):

@@ -3,9 +3,10 @@ reference's own Python produced, against the oracle, and -- at BASELINE.json's f
 through size-independent properties.
 
 north_star tolerance: (yaw, pitch) of the gaze vectors within 1e-3 of the reference CPU path.
-That bar is met (with margin) by the MCG_F32 engine.  The MCG_BF16 engine is the throughput
-configuration BASELINE.json quotes clips/s on; its deviation is bounded by BF16_TOL below and
-the measured value is printed (DESIGN.md reports it).
+That bar is met (with margin) by the MCG_F32 and MCG_F16X3 engines -- the PARITY tests.  The MCG_BF16
+engine is the 16-bit throughput mode and is NOT within it on random-weight nets; the tests that
+touch it are property / bound tests (finite, unit norm, bit-identical across schedules, deviation
+below BF16_TOL = the largest ever measured x 1.3) and are named as such.
 """
 import os
 
@@ -83,7 +84,10 @@ def test_fp32_engine_matches_reference_golden(golden_dir, engines, name, precisi
 
 
 @pytest.mark.parametrize('name', CASES)
-def test_bf16_engine_close_to_reference_golden(golden_dir, engines, name):
+def test_bf16_engine_deviation_is_bounded_not_parity(golden_dir, engines, name):
+    """A BOUND test, not a parity test: the bf16 THROUGHPUT engine is outside north_star's 1e-3 on random-weight nets (DESIGN.md 3.2);
+    what is asserted is that its output is finite, unit-norm and within the largest deviation ever measured x 1.3, so that a
+    regression of the 16-bit path (a wrong rounding, a swapped operand) still fails.  Parity is asserted for fp32 and f16x3 above."""
     g, img, B, T, ishape = load_case(golden_dir, name)
     N = B * T
     hw = np.tile(np.array(ishape[:2], dtype=np.int32), (N, 1))
@@ -411,15 +415,24 @@ def test_pointwise_stream_kernel_is_bit_identical(engines):
         e.set_option('pointwise_stream', 1)
 
 
-@pytest.mark.parametrize('index', range(16))
+FUZZ_CASES = 16
+FUZZ_MAX_CROSSINGS = {'fp32': 0, 'f16x3': 1}   # asserted RATE over the 16 cases: profiles/r02_m_parity_fuzz.md measured 0 / 2400 (fp32) and 1 / 2400 (f16x3)
+FUZZ_CROSSED_CLIP_BOUND = 0.05                 # rad, gaze-vector angle inside a clip whose chain crossed a discontinuity (the one observed: 4.5e-3)
+_fuzz_seen = {}
+
+
+@pytest.mark.parametrize('index', range(FUZZ_CASES))
 def test_parity_on_random_shapes_and_weights(engines_by_weights, index):
     """tools/parity_fuzz.py's cases 0..15 of seed 2 (random clip length, batch, frame size, img_shape inside the padded frame, three
     weight seeds) for the two parity-grade engines.  The model has discontinuities (a RoIAlign sample leaving [-1, L], a box crossing
-    a pyramid-level boundary) and (yaw, pitch) is singular at the poles, so the assertions are the ones that CAN hold for every
-    input (tests/parity_tools.py): every stage's arithmetic on the oracle's own inputs within 2e-5 of scale; end to end the gaze
-    VECTORS within 2e-4 rad and (yaw, pitch) within north_star's 1e-3 away from the poles -- unless the engine's chain crossed a
-    discontinuity, which is then reported (profiles/r02_m_parity_fuzz.md: one in 2400 inputs since the halves are fp16; the bf16-halves
-    version crossed seven in 1400, profiles/r02_j_parity_fuzz.md)."""
+    a pyramid-level boundary) and (yaw, pitch) is singular at the poles, so what is asserted is what CAN hold for every input
+    (tests/parity_tools.py):
+      * every stage's arithmetic on the oracle's own inputs within 2e-5 of scale -- always;
+      * end to end, for every CLIP of the batch whose chain crossed no discontinuity (clips are independent): gaze VECTORS within
+        2e-4 rad and (yaw, pitch) within north_star's 1e-3 away from the poles;
+      * for a clip that did cross one: the gaze vectors still within FUZZ_CROSSED_CLIP_BOUND (a crossing moves one sample or one
+        level, it does not derail the clip), and the crossing is COUNTED -- test_parity_fuzz_discontinuity_rate below asserts the
+        rate over the 16 cases (no case is skipped)."""
     from tests import parity_tools as PT
     k = synth.fuzz_case(2, index)
     sd, engs = engines_by_weights(k['wseed'])
@@ -436,8 +449,82 @@ def test_parity_on_random_shapes_and_weights(engines_by_weights, index):
         ang = 2 * torch.asin(((got.double() - ref['gaze_score'].double()).norm(dim=-1) / 2).clamp(max=1))   # acos(dot) has no resolution near 0
         d = (orc.yaw_pitch(got) - orc.yaw_pitch(ref['gaze_score'])).abs().max(dim=1).values
         away = ref['gaze_score'][:, 1].abs() < 0.99
-        print(f'fuzz case {index} {prec}: max angle {float(ang.max()):.2e} rad, max d(yaw, pitch) {float(d.max()):.2e}; {PT.describe(rep)}')
-        if rep['discontinuity']:
-            continue
-        assert float(ang.max()) < 2e-4, (prec, float(ang.max()))      # measured over 1400 inputs: fp32 <= 6.9e-5, f16x3 <= 1.1e-4
-        assert not bool(away.any()) or float(d[away].max()) < F32_TOL, (prec, float(d[away].max()))
+        clip_crossed = torch.from_numpy(rep['crossed_boxes'].reshape(k['B'], k['T'] * 3).any(axis=1))     # [B]
+        frame_ok = ~clip_crossed.repeat_interleave(k['T'])                                                 # [N]: frames of clips that crossed nothing
+        _fuzz_seen[(index, prec)] = bool(clip_crossed.any())
+        print(f'fuzz case {index} {prec}: max angle {float(ang.max()):.2e} rad, max d(yaw, pitch) {float(d.max()):.2e}, '
+              f'clips that crossed a discontinuity: {int(clip_crossed.sum())} of {k["B"]}; {PT.describe(rep)}')
+        assert bool(clip_crossed.any()) == bool(rep['discontinuity'])
+        if bool(frame_ok.any()):
+            assert float(ang[frame_ok].max()) < 2e-4, (prec, float(ang[frame_ok].max()))      # measured over 2400 inputs: fp32 <= 6.9e-5, f16x3 <= 1.1e-4
+            sel = frame_ok & away
+            assert not bool(sel.any()) or float(d[sel].max()) < F32_TOL, (prec, float(d[sel].max()))
+        if bool((~frame_ok).any()):
+            assert float(ang[~frame_ok].max()) < FUZZ_CROSSED_CLIP_BOUND, (prec, float(ang[~frame_ok].max()))
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'f16x3'])
+def test_parity_fuzz_discontinuity_rate(prec):
+    """The rate the fuzz cases above are allowed to cross a model discontinuity at: none for fp32, at most one of the 16 for f16x3
+    (measured over 2400 inputs: 0 and 1).  Runs after them (file order); a partial selection of the cases asserts on what ran."""
+    seen = [v for (i, p), v in _fuzz_seen.items() if p == prec]
+    if not seen:
+        pytest.skip('the fuzz cases did not run in this session')
+    assert sum(seen) <= FUZZ_MAX_CROSSINGS[prec], (prec, sum(seen), len(seen))
+
+
+def test_two_threads_two_engines_one_device():
+    """include/mcgaze_hip.h "Threading and streams": an engine runs one forward at a time, so concurrent forwards on one device take
+    one engine per thread (here: two f16x3 engines over the SAME weights, each thread on its own stream, sharing the device's
+    side-stream pool).  Eight forwards per thread on different inputs, submitted concurrently, must reproduce the single-threaded
+    results bit for bit; so must two threads hammering ONE engine (serialised by its mutex), each with its own workspace."""
+    import threading
+    from mcgaze_amd.engine import HipEngine
+    sd = synth.make_state_dict(0)
+    T, B = 7, 10                      # 70 frames: the trunk splits into two concurrent frame ranges
+    engines = [HipEngine(sd, precision='f16x3') for _ in range(2)]
+    imgs = [[torch.from_numpy(synth.make_clips(500 + 10 * t + i, B, T)).to('cuda:0') for i in range(4)] for t in range(2)]
+    want = [[{k: v.clone() for k, v in engines[0].forward(x, T).items()} for x in imgs[t]] for t in range(2)]
+    torch.cuda.synchronize()
+
+    def hammer(use_engines):
+        got, errs = [[None] * 8 for _ in range(2)], []
+
+        def work(t):
+            try:
+                s = torch.cuda.Stream(device='cuda:0')
+                with torch.cuda.stream(s):
+                    for r in range(8):
+                        got[t][r] = {k: v.clone() for k, v in use_engines[t].forward(imgs[t][r % 4], T).items()}
+                s.synchronize()
+            except Exception as ex:   # surfaced below: a failure inside a thread must fail the test
+                errs.append(ex)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        for t in range(2):
+            for r in range(8):
+                for k in ('gaze', 'boxes', 'scores'):
+                    assert torch.equal(got[t][r][k], want[t][r % 4][k]), (t, r, k)
+
+    hammer(engines)                                   # one engine per thread
+    third = HipEngine(sd, precision='f16x3')          # ONE engine, two threads: HipEngine.forward re-uses its workspace, so give the
+    class _OwnWs:                                     # second thread a view of the engine with its own workspace
+        def __init__(self, e):
+            self.e, self.ws = e, None
+        def forward(self, x, T):
+            import ctypes as C
+            from mcgaze_amd import lib as L
+            from mcgaze_amd.engine import _ptr, _stream, _ws
+            e = self.e
+            N, _, H, W = x.shape
+            if self.ws is None:
+                self.ws = _ws(e.lib.mcg_engine_workspace_bytes(e._handle, N, H, W, 0), e.device)
+            out = dict(gaze=torch.empty(4, N, 3, device=e.device), boxes=torch.empty(N, 3, 4, device=e.device), scores=torch.empty(N, 3, device=e.device))
+            L.check(e.lib.mcg_clip_forward(e._handle, _stream(e.device), _ptr(x), N, T, H, W, C.c_void_p(0), 0, _ptr(out['gaze']), _ptr(out['boxes']),
+                                           _ptr(out['scores']), _ptr(self.ws), self.ws.numel()), 'mcg_clip_forward')
+            return out
+    hammer([_OwnWs(third), _OwnWs(third)])

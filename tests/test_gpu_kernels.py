@@ -123,6 +123,26 @@ def test_conv2d_f16x3(eng, case):
     assert err < X3_TOL, err
 
 
+@pytest.mark.parametrize('wscale', [1.0, 1e-2, 1e-3])
+def test_f16x3_small_weights(eng, wscale):
+    """a weight below 0.125 has its LOW half in fp16's subnormal range (absolute error 2^-25), so the split keeps fewer than
+    22 bits of it: measured here on a 1x1 conv whose weights are scaled to ~1e-2 / ~1e-3 (a BN fold with a small gamma / sigma ratio),
+    the bias-free output compared with the f64 product.  The bound is the arithmetic's own: relative error <= 2^-25 / |w| per weight,
+    sqrt(K)-averaged -- still two orders of magnitude inside the bf16 kernel at 1e-3."""
+    g = torch.Generator().manual_seed(99)
+    N, H, W, Cin, Cout = 2, 12, 12, 256, 256
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * wscale
+    ref = F.conv2d(x.double(), w.double())
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to('cuda:0')
+    y = eng.conv2d(nhwc(x), nhwc(w), None, split=True)
+    torch.cuda.synchronize()
+    err = scale_err(y.permute(0, 3, 1, 2), ref.float())
+    print(f'f16x3 1x1 conv, weights ~{wscale:g}: {err:.2e} of scale')
+    bound = max(X3_TOL, 4 * 2.0 ** -25 / wscale)      # measured: 1.0 -> 3e-7, 1e-2 -> 6e-7, 1e-3 -> 4e-6
+    assert err < bound, (wscale, err, bound)
+
+
 def test_conv2d_f16x3_randomized_shapes(eng):
     """The randomized sweep of test_conv2d_randomized_shapes for the f16x3 kernel (channel counts are multiples of 32: its K tile)."""
     rs = np.random.RandomState(4048)

@@ -21,10 +21,8 @@ eng.forward(img, 7)
 torch.cuda.synchronize()
 rec = eng.profile_stop(4096)
 tot = 0.0
-print(f'{"#":>3} {"cfg":>3} {"M":>8} {"N":>6} {"K":>6} {"ms":>8} {"TF/s":>7} {"GB/s(min)":>9}')
-es = 2 if prec == 'bf16' else 4
-for i, (ms, fl, cf, (M, N, K)) in enumerate(rec):
+print(f'{"#":>3} {"cfg":>3} {"M":>8} {"N":>6} {"K":>6} {"ms":>8} {"TF/s":>7} {"algoGB":>7} {"GB/s":>6}')
+for i, (ms, fl, cf, (M, N, K), by) in enumerate(rec):
     tot += ms
-    gb = (M * N + N * K) * es / 1e9  # lower bound: write out + weights (input reuse varies)
-    print(f'{i:3d} {cf:3d} {M:8d} {N:6d} {K:6d} {ms:8.4f} {fl / ms / 1e9:7.1f} {gb / (ms * 1e-3):9.0f}')
+    print(f'{i:3d} {cf:3d} {M:8d} {N:6d} {K:6d} {ms:8.4f} {fl / ms / 1e9:7.1f} {by / 1e9:7.3f} {by / 1e9 / (ms * 1e-3):6.0f}')
 print(f'total contraction time {tot:.3f} ms over {len(rec)} launches')

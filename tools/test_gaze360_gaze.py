@@ -64,7 +64,8 @@ def main(argv=None):
     a = parse_args(argv)
     world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
     device = a.device if world == 1 else f'cuda:{local}'
-    torch.cuda.set_device(torch.device(device))
+    d = torch.device(device)
+    torch.cuda.set_device(d.index if d.index is not None else 0)   # 'cuda' without an index is device 0 (set_device rejects it)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
