@@ -460,10 +460,12 @@ def mae_proxy(engines, dev, n_videos, T, frames_per_video=31, src=320, cpu_threa
     for name, eng in engines.items():
         rec = harness.run_videos(eng, videos, clip_len=T, batch_clips=64)
         torch.cuda.synchronize(dev)
-        vs = metric.gaze_error(rec, oracle_gt, verbose=False)['mae_360']
         sg = metric.gaze_error(rec, synth_gt, verbose=False)['mae_360']
-        worst = max(float(torch.rad2deg(torch.acos((metric.smooth_filter(torch.tensor(a['fusion_gazes'])) * torch.tensor(b['gaze'])).sum(-1).clamp(-1, 1))).max())
-                    for a, b in zip(rec, oracle_gt['annotations']))
+        # vs the oracle: the reference's formula is acos(dot) UNCLAMPED (NaN once rounding lifts a dot product of near-identical unit
+        # vectors above 1) and has no resolution near zero; here the angle is 2 asin(|a - b| / 2) on the same smoothed predictions
+        angs = torch.cat([torch.rad2deg(2 * torch.asin(((metric.smooth_filter(torch.tensor(a['fusion_gazes'])).double() - torch.tensor(b['gaze']).double()).norm(dim=-1) / 2).clamp(max=1)))
+                          for a, b in zip(rec, oracle_gt['annotations'])])
+        vs, worst = float(angs.mean()), float(angs.max())
         out['engines'][name] = {'vs_oracle_deg': round(vs, 5), 'max_frame_vs_oracle_deg': round(worst, 4), 'synthetic_gt_deg': round(sg, 4),
                                 'shift_deg': round(sg - base, 5), 'within_0p05_deg': bool(abs(sg - base) <= 0.05)}
     return out

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 8
+#define MCG_ABI_VERSION 9
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
 /* MCG_F16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
@@ -91,6 +91,12 @@ typedef struct {
   int flags;            /* MCG_FLAG_* */
 } mcg_conv_desc;
 int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);
+
+/* The fused bottleneck tail as a stand-alone operator (MCG_F16X3 arithmetic; resnet.py:263-302): x = conv2's input
+ * [frames][H][W][64] f32; src2 = the residual [frames][H][W][256] (nsrc = 1) or the downsample conv's input [frames][H][W][64]
+ * (nsrc = 2); y [..][256]; z [..][cn] (cn = 0: not written).  See mcg_fused_block for wstream / bias. */
+int mcg_bottleneck_x3(mcg_stream s, const float* x, const float* src2, const void* wstream, const float* bias, float* y, float* z,
+                      int frames, int H, int W, int nsrc, int cn);
 
 /* Stem: conv 7x7 s2 p3 (3->64) + BN + ReLU then max-pool 3x3 s2 p1 (resnet.py:636-639).
  * img is the reference's NCHW f32 frame tensor.  w_stem is the packed stem weight
@@ -179,6 +185,20 @@ typedef struct {
                          conv3 (+ residual) and the next block's conv1 as one kernel (pw_pair.hpp); NULL -> layer-granular launches */
 } mcg_conv_weights;
 
+/* A fused bottleneck tail of the MCG_F16X3 engine (bneck_x3.hpp): conv2 (3x3) -> conv3 (1x1, + downsample as a second K source or
+ * + residual) -> the NEXT block's conv1 (1x1) in one kernel; the 64-channel intermediates never leave the CU and the block output is
+ * read from HBM once less.  wstream: the three weight matrices as 16 KiB MFMA-fragment-major slabs of fp16 high / low parts in
+ * the order the kernel consumes them (mcgaze_amd/packing.py::bneck_stream gives the exact layout; bytes =
+ * 16384 * (9 + 4 * (nsrc + cn / 64))).  bias: f32 [cm | c | cn].  Applies when cm = 64, c = 256, cn in {0, 64, 128} (layer1 of a
+ * ResNet-50); other layers keep the layer-granular launches. */
+typedef struct {
+  const void* wstream;
+  const float* bias;
+  int conv2_index;                  /* index into convs[] of the conv2 this unit replaces (its conv3 [+ downsample] follow) */
+  int cm, c, cn;                    /* mid channels, output channels, output channels of the next block's conv1 (0 = none) */
+  int nsrc;                         /* 1: identity block (residual = block input); 2: first block (conv3 | downsample, no residual) */
+} mcg_fused_block;
+
 typedef struct {
   int blocks[4];                    /* bottlenecks per layer, (3,4,6,3) for R-50 */
   mcg_conv_weights stem;            /* packed stem, see mcg_stem_forward */
@@ -193,6 +213,8 @@ typedef struct {
   const void* const* stage_weights; /* host array [num_stages][MCG_SW_COUNT] of device pointers */
   const void* const* gaze_weights;  /* host array [MCG_GW_COUNT]: the LAST stage's gaze head */
   float bbox_stds[4];
+  const mcg_fused_block* fused;     /* optional (MCG_F16X3): host array of fused bottleneck tails, or NULL */
+  int num_fused;
 } mcg_model_weights;
 
 typedef struct mcg_engine mcg_engine;
@@ -228,7 +250,8 @@ void mcg_engine_destroy(mcg_engine* e);
  *   staged_gemm, conv3x3_c64, stem_fused, decoder_chain   0/1 kernel-variant switches (defaults 0, 1, 1, 1)
  *   pointwise_pair    0/1 conv3 (+ residual) of a block and conv1 of the next as one kernel in layer1 (bf16; default 1)
  *   pointwise_stream  0/1 HBM-bound 1x1 convs (layer2, layer3 conv3, P2 / P3 laterals) by the persistent register-resident-weight
- *                     kernel pw_single.hpp (bf16; default 1) */
+ *                     kernel pw_single.hpp (bf16; default 1)
+ *   bottleneck_fused  0/1 the fused bottleneck tails handed over in mcg_model_weights.fused (f16x3; default 1) */
 int mcg_engine_set_option(mcg_engine* e, const char* name, int value);
 /* chunk_frames: the trunk runs in chunks of this many frames so that layer outputs stay
  * resident in the 256 MiB Infinity Cache (0 = all frames in one pass). */

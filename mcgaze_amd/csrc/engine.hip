@@ -10,6 +10,7 @@
 #include "igemm.hpp"
 #include "pw_pair.hpp"
 #include "pw_single.hpp"
+#include "bneck_x3.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -30,6 +31,8 @@ struct mcg_engine {
   mcg_conv_weights stem;
   std::vector<mcg_conv_weights> convs;
   mcg_conv_weights lateral[4], fpn_out[4], c3_ds[4];
+  std::vector<mcg_fused_block> fused;   // f16x3: fused bottleneck tails (bneck_x3.hpp), looked up by conv2 index
+  bool bneck_fused = true;
   const float* init_boxes;
   const void* init_feats;
   int num_stages;
@@ -46,6 +49,7 @@ struct mcg_engine {
   int trunk_streams = 2;       // concurrent frame ranges of the trunk
   int max_range_frames = 0;    // 0 = what fits the 2 GiB descriptor window
   bool pw_single = true;       // HBM-bound 1x1 convs of layer2 / the P2 lateral (bf16): persistent register-resident-weight kernel (pw_single.hpp)
+  int lab_skip = 0;            // LAB ONLY (timing what-ifs): bits 0-2 = conv1/conv2/conv3, bits 3-6 = layer1..4, bit 7 = laterals, bit 8 = fpn 3x3
   bool pw_pair = true;         // layer1 / layer2 (bf16): conv3 (+ residual) and the next block's conv1 as one kernel (pw_pair.hpp)
   std::mutex mu;               // one forward at a time per engine: the fork/join events and side streams are shared state
 };
@@ -154,6 +158,7 @@ extern "C" int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, m
   memcpy(e->lateral, w->lateral, sizeof(e->lateral));
   memcpy(e->fpn_out, w->fpn_out, sizeof(e->fpn_out));
   memcpy(e->c3_ds, w->c3_ds, sizeof(e->c3_ds));
+  if (w->fused && w->num_fused > 0 && dt == MCG_F16X3) e->fused.assign(w->fused, w->fused + w->num_fused);
   e->init_boxes = w->init_boxes;
   e->init_feats = w->init_feats;
   e->num_stages = w->num_stages;
@@ -187,6 +192,8 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "decoder_chain")) e->ctx.chain = value != 0;
   else if (!strcmp(name, "pointwise_pair")) e->pw_pair = value != 0;
   else if (!strcmp(name, "pointwise_stream")) e->pw_single = value != 0;
+  else if (!strcmp(name, "lab_skip")) e->lab_skip = value;
+  else if (!strcmp(name, "bottleneck_fused")) e->bneck_fused = value != 0;
   else { mcg_set_error("mcg_engine_set_option: unknown option '%s'", name); return MCG_ERR_ARG; }
   return MCG_OK;
 }
@@ -316,16 +323,47 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
   MCG_TRY(stem_forward_ctx(s, dt, img + (size_t)f0 * 3 * H * W, e->stem.w, e->stem.bias, t.x0, n, H, W, t.stem_ws, t.stem_bytes, e->ctx));
   const void* x = t.x0;
   int h = H / 4, w = W / 4, ci = 0;
-  bool o1_ready = false;   // t.o1 already holds this block's conv1 output (written by the previous block's pointwise-pair kernel)
+  bool o1_ready = false;   // o1 already holds this block's conv1 output (written by the previous block's pointwise-pair / fused-tail kernel)
+  char *o1 = t.o1, *o2 = t.o2;   // conv1 / conv2 outputs; the fused tail writes the NEXT conv1 output into o2 and the two swap
   for (int l = 0; l < 4; ++l) {
     for (int b = 0; b < e->blocks[l]; ++b) {
       const mcg_conv_weights& c1 = e->convs[ci], &c2 = e->convs[ci + 1], &c3 = e->convs[ci + 2];
       const bool has_ds = b == 0;
       const int ho = (h + 2 * c2.pad - c2.k) / c2.stride + 1, wo = (w + 2 * c2.pad - c2.k) / c2.stride + 1;
       void* y = (b == e->blocks[l] - 1) ? (void*)t.c[l] : (x == t.xa ? (void*)t.xb : (void*)t.xa);
-      if (!o1_ready) MCG_TRY(conv_call(e, s, dt, c1, x, n, h, w, t.o1, 1, nullptr, MCG_RES_NONE, 0, 0));
+      const int lsk = (e->lab_skip >> (3 + l)) & 1 ? e->lab_skip & 7 : 0;
+      if (!o1_ready && !(lsk & 1)) MCG_TRY(conv_call(e, s, dt, c1, x, n, h, w, o1, 1, nullptr, MCG_RES_NONE, 0, 0));
       o1_ready = false;
-      MCG_TRY(conv_call(e, s, dt, c2, t.o1, n, h, w, t.o2, 1, nullptr, MCG_RES_NONE, 0, 0));
+      // f16x3: conv2 -> conv3 (+ downsample / + residual) -> the next block's conv1 as ONE kernel (bneck_x3.hpp)
+      const mcg_fused_block* fb = nullptr;
+      if (dt == MCG_F16X3 && e->bneck_fused && e->ctx.tile < 0 && !lsk)
+        for (const mcg_fused_block& f : e->fused)
+          if (f.conv2_index == ci + 1) fb = &f;
+      if (fb) {
+        const int k2 = has_ds ? e->convs[ci + 3].cin : 0, s2 = has_ds ? e->convs[ci + 3].stride : 1;
+        const int ci_nx = ci + (has_ds ? 4 : 3);
+        const bool nx_ok = fb->cn == 0 || (ci_nx < (int)e->convs.size() && e->convs[ci_nx].k == 1 && e->convs[ci_nx].stride == 1 && e->convs[ci_nx].cout == fb->cn && e->convs[ci_nx].cin == fb->c);
+        if (c2.k == 3 && c2.stride == 1 && c2.pad == 1 && c2.cin == fb->cm && c2.cout == fb->cm && c3.cout == fb->c && fb->nsrc == (has_ds ? 2 : 1) && nx_ok &&
+            bneck_x3_applicable(fb->cm, fb->c, fb->cn, fb->nsrc, k2, s2)) {
+          BneckParams bp;
+          memset(&bp, 0, sizeof(bp));
+          bp.x = (const float*)o1; bp.res = (const float*)x; bp.wstream = (const char*)fb->wstream; bp.bias = fb->bias;
+          bp.y = (float*)y; bp.z = (float*)o2; bp.H = h; bp.W = w;
+          const double M = (double)n * h * w;
+          ProfRec* rec = prof_begin(e->ctx, s, 70, n * h * w, fb->c + fb->cn, 9 * fb->cm + fb->cm + k2 + fb->c,
+                                    2.0 * M * (9.0 * fb->cm * fb->cm + (double)(fb->cm + k2) * fb->c + (double)fb->c * fb->cn),
+                                    4.0 * (M * (fb->cm + (has_ds ? k2 : fb->c) + fb->c + fb->cn) + 9.0 * fb->cm * fb->cm + (double)(fb->cm + k2) * fb->c + (double)fb->c * fb->cn));
+          const int frc = launch_bneck_x3(s, bp, n, fb->nsrc, fb->cn);
+          prof_end(rec, s);
+          if (frc) { mcg_set_error("bneck_x3 launch failed"); return MCG_ERR_HIP; }
+          if (fb->cn > 0) { char* tmp = o1; o1 = o2; o2 = tmp; o1_ready = true; }
+          x = y; h = ho; w = wo;
+          ci = ci_nx;
+          continue;
+        }
+      }
+      if (!(lsk & 2)) MCG_TRY(conv_call(e, s, dt, c2, o1, n, h, w, o2, 1, nullptr, MCG_RES_NONE, 0, 0));
+      if (lsk & 4) { x = y; h = ho; w = wo; ci += has_ds ? 4 : 3; continue; }
       // conv3 (+ downsample / + residual) together with the NEXT block's conv1 (pw_pair.hpp): layer1 / layer2, where both are
       // HBM-bound.  The next conv1 is the following block's, or the next layer's first (1x1, stride 1 on this block's output).
       const int ci_next = ci + (has_ds ? 4 : 3);
@@ -336,11 +374,11 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
           c1n->cin == c3.cout && pw_pair_applicable(c3.cin, k2, has_ds ? e->convs[ci + 3].stride : 1, c3.cout, c1n->cout, (long long)n * ho * wo) && (long long)n * ho * wo < 0x7fffffffll) {
         PwPairParams pp;
         memset(&pp, 0, sizeof(pp));
-        pp.a1 = t.o2; pp.K1 = c3.cin;
+        pp.a1 = o2; pp.K1 = c3.cin;
         if (has_ds) { pp.a2 = x; pp.K2 = k2; pp.stride2 = e->convs[ci + 3].stride; pp.H2 = h; pp.W2 = w; }
         else pp.res = x;
         pp.w3f = c3w->wf; pp.b3 = c3w->bias; pp.y = y;
-        pp.w1f = c1n->wf; pp.b1 = c1n->bias; pp.z = t.o1;
+        pp.w1f = c1n->wf; pp.b1 = c1n->bias; pp.z = o1;
         pp.M = n * ho * wo; pp.C = c3.cout; pp.C2 = c1n->cout; pp.Ho = ho; pp.Wo = wo;
         // cfg 60: both contractions of the pair count (2 M (K C + C C2))
         ProfRec* rec = prof_begin(e->ctx, s, 60, pp.M, pp.C + pp.C2, pp.K1 + pp.K2, 2.0 * pp.M * ((double)(pp.K1 + pp.K2) * pp.C + (double)pp.C * pp.C2),
@@ -359,7 +397,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
         const mcg_conv_weights& f = e->c3_ds[l];
         mcg_conv_desc d;
         memset(&d, 0, sizeof(d));
-        d.x = t.o2; d.w = f.w; d.bias = f.bias; d.y = y;
+        d.x = o2; d.w = f.w; d.bias = f.bias; d.y = y;
         d.N = n; d.H = ho; d.W = wo; d.Cin = c3.cin; d.Cout = c3.cout; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0; d.relu = 1;
         d.x2 = x; d.Cin2 = e->convs[ci + 3].cin; d.stride2 = e->convs[ci + 3].stride; d.H2 = h; d.W2 = w;
         MCG_TRY(conv2d_ctx(s, dt, &d, e->ctx));
@@ -369,7 +407,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
           MCG_TRY(conv_call(e, s, dt, e->convs[ci + 3], x, n, h, w, t.ds, 0, nullptr, MCG_RES_NONE, 0, 0));
           identity = t.ds;
         }
-        MCG_TRY(conv_call(e, s, dt, c3, t.o2, n, ho, wo, y, 1, identity, MCG_RES_ADD, 0, 0));
+        MCG_TRY(conv_call(e, s, dt, c3, o2, n, ho, wo, y, 1, identity, MCG_RES_ADD, 0, 0));
       }
       x = y; h = ho; w = wo;
       ci += has_ds ? 4 : 3;
@@ -380,11 +418,13 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
   int hs[4], wsz[4];
   for (int i = 0; i < 4; ++i) { hs[i] = (H / 4) >> i; wsz[i] = (W / 4) >> i; }
   for (int i = 3; i >= 0; --i) {
+    if (e->lab_skip & 128) break;
     const void* res = i == 3 ? nullptr : t.l[i + 1];
     MCG_TRY(conv_call(e, s, dt, e->lateral[i], t.c[i], n, hs[i], wsz[i], t.l[i], 0, res, res ? MCG_RES_UPSAMPLE_ADD : MCG_RES_NONE,
                       i == 3 ? 0 : hs[i + 1], i == 3 ? 0 : wsz[i + 1]));
   }
   for (int i = 0; i < 4; ++i) {
+    if (e->lab_skip & 256) break;
     char* dst = (char*)pyr[i] + (size_t)f0 * hs[i] * wsz[i] * 256 * es;
     MCG_TRY(conv_call(e, s, dt, e->fpn_out[i], t.l[i], n, hs[i], wsz[i], dst, 0, nullptr, MCG_RES_NONE, 0, 0));
   }
@@ -487,6 +527,18 @@ static int trunk_forward(mcg_engine* e, mcg_stream s_, const float* img, int N, 
     }
   }
   return rc;
+}
+
+extern "C" int mcg_bottleneck_x3(mcg_stream s, const float* x, const float* src2, const void* wstream, const float* bias, float* y, float* z,
+                                 int frames, int H, int W, int nsrc, int cn) {
+  MCG_CHECK_ARG(x && src2 && wstream && bias && y && (z || cn == 0), "mcg_bottleneck_x3: null pointer");
+  MCG_CHECK_ARG(frames > 0 && H > 0 && W > 0, "mcg_bottleneck_x3: empty problem");
+  MCG_CHECK_ARG(bneck_x3_applicable(64, 256, cn, nsrc, 64, 1), "mcg_bottleneck_x3: unsupported shape (nsrc=%d cn=%d)", nsrc, cn);
+  BneckParams bp;
+  memset(&bp, 0, sizeof(bp));
+  bp.x = x; bp.res = src2; bp.wstream = (const char*)wstream; bp.bias = bias; bp.y = y; bp.z = z; bp.H = H; bp.W = W;
+  if (launch_bneck_x3((hipStream_t)s, bp, frames, nsrc, cn)) { mcg_set_error("mcg_bottleneck_x3: launch failed"); return MCG_ERR_HIP; }
+  return MCG_OK;
 }
 
 extern "C" int mcg_backbone_fpn_forward(mcg_engine* e, mcg_stream s, const float* img, int N, int H, int W, int chunk,

@@ -88,6 +88,19 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual
     return y
 
 
+def bottleneck_x3(x, src2, wstream, bias, cn, nsrc):
+    """The fused bottleneck tail (mcg_bottleneck_x3): x [N,H,W,64] f32 = conv2's input, src2 = residual [N,H,W,256] (nsrc 1) or the
+    downsample conv's input [N,H,W,64] (nsrc 2); wstream / bias from packing.bneck_stream.  -> (y [N,H,W,256], z [N,H,W,cn] or None)."""
+    _require_gpu()
+    lib = L.load()
+    N, H, W, _ = x.shape
+    y = torch.empty(N, H, W, 256, dtype=torch.float32, device=x.device)
+    z = torch.empty(N, H, W, cn, dtype=torch.float32, device=x.device) if cn else None
+    L.check(lib.mcg_bottleneck_x3(_stream(), _ptr(x.contiguous()), _ptr(src2.contiguous()), _ptr(wstream), _ptr(bias), _ptr(y), _ptr(z),
+                                  N, H, W, nsrc, cn), 'mcg_bottleneck_x3')
+    return y, z
+
+
 def stem(img, w_stem, bias, dtype, flags=0, split=False):
     """img [N,3,H,W] f32 -> [N,H/4,W/4,64] NHWC.  mcg_stem_forward."""
     _require_gpu()
@@ -186,6 +199,10 @@ class HipEngine:
         mw.stage_weights = C.cast(self._stage_tab, C.POINTER(C.c_void_p))
         mw.gaze_weights = C.cast(self._gaze_tab, C.POINTER(C.c_void_p))
         mw.bbox_stds = (C.c_float * 4)(*bbox_stds)
+        if w.fused:
+            self._fused = (L.FusedBlock * len(w.fused))(*[L.FusedBlock(f['wstream'].data_ptr(), f['bias'].data_ptr(), f['conv2_index'], f['cm'], f['c'],
+                                                                      f['cn'], f['nsrc']) for f in w.fused])
+            mw.fused, mw.num_fused = C.cast(self._fused, C.POINTER(L.FusedBlock)), len(w.fused)
         self._handle = C.c_void_p()
         with torch.cuda.device(self.device):   # the engine's side streams and events belong to THIS device
             L.check(self.lib.mcg_engine_create(C.byref(self._handle), C.byref(mw), self.code), 'mcg_engine_create')
@@ -194,7 +211,7 @@ class HipEngine:
 
     def set_option(self, name, value):
         """mcg_engine_set_option: 'trunk_streams', 'max_range_frames', 'tile', 'staged_gemm', 'conv3x3_c64', 'stem_fused',
-        'decoder_chain', 'pointwise_pair', 'pointwise_stream' (include/mcgaze_hip.h)."""
+        'decoder_chain', 'pointwise_pair', 'pointwise_stream', 'bottleneck_fused' (include/mcgaze_hip.h)."""
         L.check(self.lib.mcg_engine_set_option(self._handle, name.encode(), int(value)), f'mcg_engine_set_option({name})')
 
     def profile_start(self, capacity=4096):

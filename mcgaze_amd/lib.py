@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('MCGAZE_LIB') or os.path.join(_HERE, 'libmcgaze_hip.so
 
 MCG_OK = 0
 MCG_F32, MCG_BF16, MCG_F16X3 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 RES_NONE, RES_ADD, RES_UPSAMPLE_ADD = 0, 1, 2
 FLAG_STAGED_GEMM, FLAG_NO_SPECIALISED = 1, 2
 
@@ -30,7 +30,7 @@ EXPORTS = ['mcg_abi_version', 'mcg_last_error', 'mcg_device_info', 'mcg_nchw_to_
            'mcg_gaze_head_workspace_bytes', 'mcg_gaze_head', 'mcg_engine_create', 'mcg_engine_destroy',
            'mcg_engine_workspace_bytes', 'mcg_trunk_workspace_bytes', 'mcg_decoder_workspace_bytes', 'mcg_backbone_fpn_forward',
            'mcg_decoder_forward', 'mcg_clip_forward', 'mcg_preprocess_frames', 'mcg_engine_set_option', 'mcg_engine_profile_start',
-           'mcg_engine_profile_stop', 'mcg_bench_backbone_forward']
+           'mcg_engine_profile_stop', 'mcg_bench_backbone_forward', 'mcg_bottleneck_x3']
 
 
 class ConvDesc(C.Structure):
@@ -46,11 +46,16 @@ class ConvWeights(C.Structure):
                 ('stride', C.c_int), ('pad', C.c_int), ('wf', C.c_void_p)]
 
 
+class FusedBlock(C.Structure):
+    _fields_ = [('wstream', C.c_void_p), ('bias', C.c_void_p), ('conv2_index', C.c_int), ('cm', C.c_int), ('c', C.c_int), ('cn', C.c_int),
+                ('nsrc', C.c_int)]
+
+
 class ModelWeights(C.Structure):
     _fields_ = [('blocks', C.c_int * 4), ('stem', ConvWeights), ('convs', C.POINTER(ConvWeights)), ('num_convs', C.c_int),
                 ('lateral', ConvWeights * 4), ('fpn_out', ConvWeights * 4), ('c3_ds', ConvWeights * 4), ('init_boxes', C.c_void_p),
                 ('init_feats', C.c_void_p), ('num_stages', C.c_int), ('stage_weights', C.POINTER(C.c_void_p)),
-                ('gaze_weights', C.POINTER(C.c_void_p)), ('bbox_stds', C.c_float * 4)]
+                ('gaze_weights', C.POINTER(C.c_void_p)), ('bbox_stds', C.c_float * 4), ('fused', C.POINTER(FusedBlock)), ('num_fused', C.c_int)]
 
 
 class FrameDesc(C.Structure):
@@ -108,6 +113,7 @@ def load():
     lib.mcg_engine_profile_start.argtypes = [vp, i]
     lib.mcg_engine_profile_stop.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i), C.POINTER(i), i]
     lib.mcg_bench_backbone_forward.argtypes = [vp, vp, vp, i, i, i, vp, sz]
+    lib.mcg_bottleneck_x3.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('mcg_abi_version',):

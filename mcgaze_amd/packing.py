@@ -76,6 +76,45 @@ def split_pack(w):
     return v.reshape(*lead, 2 * K).contiguous()
 
 
+def _slab(w64, chain):
+    """f32 [64 out][64 k] -> one 16 KiB weight slab of bneck_x3.hpp: fp16 [2 channel tiles][4 K-steps][high, low][64 lanes][8], lane l
+    holding row 32 ct + (l & 31) and, for e < 8, column 16 s + 8 (l >> 5) + e (chain = False: the 3x3 conv, whose B operand comes
+    from the window planes in natural order) or 16 s + 4 (l >> 5) + (e & 3) + 8 (e >> 2) (chain = True: the B operand is the previous
+    contraction's accumulator registers, which hold channels {0..3, 8..11} + 4 (l >> 5) of a K-step)."""
+    assert tuple(w64.shape) == (64, 64)
+    w64 = w64.float()
+    hi = w64.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (w64 - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    lane, e, s, ct = torch.arange(64), torch.arange(8), torch.arange(4), torch.arange(2)
+    half = lane >> 5
+    if chain:
+        col = 16 * s[:, None, None] + 4 * half[None, :, None] + (e & 3)[None, None, :] + 8 * (e >> 2)[None, None, :]
+    else:
+        col = 16 * s[:, None, None] + 8 * half[None, :, None] + e[None, None, :]
+    row = 32 * ct[:, None, None, None] + (lane & 31)[None, None, :, None]                     # [ct, 1, lane, 1]
+    col = col[None].expand(2, 4, 64, 8)
+    row = row.expand(2, 4, 64, 8)
+    return torch.stack([hi[row, col], lo[row, col]], dim=2)                                  # [ct][s][hl][lane][e]
+
+
+def bneck_stream(w2, b2, w3, b3, w1n=None, b1n=None):
+    """Weight stream + bias block of one fused bottleneck tail (include/mcgaze_hip.h: mcg_fused_block; bneck_x3.hpp).
+    w2 [64][3][3][64] OHWI, w3 [256][64 (+ 64: the downsample conv's K-concatenated input)], w1n [cn][256] or None -- all f32 with BN
+    folded.  Slab order = consumption order: the 9 taps of w2; then per 64-channel chunk oc of y: w3[oc chunk][K part] for each K
+    part of 64, w1n[64-row pair][oc chunk] for each pair.  -> (fp16 tensor of 8192 halves per slab, f32 bias [64 | 256 | cn])."""
+    assert tuple(w2.shape) == (64, 3, 3, 64) and w3.shape[0] == 256 and w3.shape[1] in (64, 128)
+    cn = 0 if w1n is None else w1n.shape[0]
+    assert cn in (0, 64, 128) and (w1n is None or w1n.shape[1] == 256)
+    slabs = [_slab(w2[:, kh, kw, :], chain=False) for kh in range(3) for kw in range(3)]
+    for oc in range(4):
+        for part in range(w3.shape[1] // 64):
+            slabs.append(_slab(w3[oc * 64:(oc + 1) * 64, part * 64:(part + 1) * 64], chain=True))
+        for pair in range(cn // 64):
+            slabs.append(_slab(w1n[pair * 64:(pair + 1) * 64, oc * 64:(oc + 1) * 64], chain=True))
+    bias = torch.cat([b2.float(), b3.float()] + ([b1n.float()] if cn else []))
+    return torch.stack(slabs).reshape(-1).contiguous(), bias.contiguous()
+
+
 def dyn_permutation(d=256, feat=64):
     """Row permutation of dynamic_layer: new row n*d+k <- old row k*feat+n (param_in^T, [feat][d]);
     new row d*feat + n*feat+k <- old row d*feat + k*d+n (param_out^T, [d][feat]); transformer.py:1134-1137."""
@@ -109,6 +148,8 @@ class PackedWeights:
         stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
         self.stem = dict(w=cmat(stem), bias=vec(b), cin=32, cout=64, k=7, stride=2, pad=3)
         self.convs = []
+        self.fused = []  # f16x3: fused bottleneck tails (bneck_stream), dicts of wstream / bias / conv2_index / cm / c / cn / nsrc
+        folded = []      # (w OIHW f32, b f32) of every entry of self.convs, for the fused tails
         self.c3_ds = []  # per layer: first block's conv3 + downsample as one K-concatenated 1x1 conv
         for li, nb in enumerate(self.blocks):
             for bi in range(nb):
@@ -117,14 +158,36 @@ class PackedWeights:
                 for conv, bn, k, s, pad in (('conv1', 'bn1', 1, 1, 0), ('conv2', 'bn2', 3, stride, 1), ('conv3', 'bn3', 1, 1, 0)):
                     w, b = fold_bn(sd, f'{p}.{conv}.weight', f'{p}.{bn}')
                     self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=k, stride=s, pad=pad, wf=wf1x1(w) if k == 1 else None))
+                    folded.append((w, b))
                 if f'{p}.downsample.0.weight' in sd:
                     w3, b3 = w, b  # conv3 of this block (last of the loop above)
                     w, b = fold_bn(sd, f'{p}.downsample.0.weight', f'{p}.downsample.1')
                     self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=1, stride=stride, pad=0))
+                    folded.append((w, b))
                     if fuse_downsample:
                         wcat = torch.cat([ohwi(w3), ohwi(w)], dim=3)  # [Cout,1,1,planes + inplanes]
                         self.c3_ds.append(dict(w=cmat(wcat), bias=vec(b3 + b), cin=wcat.shape[3], cout=wcat.shape[0], k=1, stride=1, pad=0,
                                                wf=wf1x1(wcat.permute(0, 3, 1, 2))))
+        if split and fuse_downsample:
+            # layer1 (64 mid channels, 256 out, stride 1): every block's conv2 -> conv3 (+ downsample | + residual) -> next conv1
+            ci = 0
+            for bi in range(self.blocks[0]):
+                has_ds = bi == 0
+                nxt = ci + (4 if has_ds else 3)
+                (w2, b2), (w3, b3) = folded[ci + 1], folded[ci + 2]
+                w3m, b3m = w3.reshape(w3.shape[0], -1), b3
+                if has_ds:
+                    wd, bd = folded[ci + 3]
+                    if self.convs[ci + 3]['stride'] != 1:
+                        break
+                    w3m, b3m = torch.cat([w3m, wd.reshape(wd.shape[0], -1)], dim=1), b3 + bd
+                w1n, b1n = (folded[nxt][0].reshape(folded[nxt][0].shape[0], -1), folded[nxt][1]) if nxt < len(folded) else (None, None)
+                if tuple(w2.shape) != (64, 64, 3, 3) or w3m.shape[0] != 256 or (w1n is not None and (w1n.shape[0] not in (64, 128) or self.convs[nxt]['stride'] != 1)):
+                    break
+                ws, bs = bneck_stream(ohwi(w2), b2, w3m, b3m, w1n, b1n)
+                self.fused.append(dict(wstream=self._dev(ws), bias=self._dev(bs), conv2_index=ci + 1, cm=64, c=256,
+                                       cn=0 if w1n is None else w1n.shape[0], nsrc=2 if has_ds else 1))
+                ci = nxt
         self.lateral, self.fpn_out = [], []
         for i in range(4):
             w = sd[f'neck.lateral_convs.{i}.conv.weight']

@@ -395,6 +395,31 @@ def test_pointwise_pair_fusion_is_bit_identical(engines):
         e.set_option('pointwise_pair', 1)
 
 
+def test_fused_bottleneck_tails_match_the_layer_granular_trunk(engines):
+    """The f16x3 engine with layer1 through bneck_x3.hpp (default) against the same engine with the layer-granular launches
+    (`bottleneck_fused` = 0).  Not bit-identical by construction -- the chained contractions visit the 16 channels of a K-step in a
+    permuted order -- but the same products in f32: every pyramid level within 2e-6 of its scale, the gaze within 1e-5 rad, and the
+    fused path itself bit-identical between a batch and its clips (test_batched_equals_per_clip_bitwise covers that for the default)."""
+    e = engines['f16x3']
+    try:
+        for shape in ((3, 224, 224), (2, 96, 160), (5, 32, 32), (1, 448, 448)):
+            img = torch.from_numpy(synth.make_clips(61, 1, *shape)).to('cuda:0')
+            e.set_option('bottleneck_fused', 0)
+            ref = [p.clone() for p in e.backbone_fpn(img)]
+            gref = e.forward(img, shape[0])['gaze'].clone()
+            e.set_option('bottleneck_fused', 1)
+            out = e.backbone_fpn(img)
+            gout = e.forward(img, shape[0])['gaze']
+            torch.cuda.synchronize()
+            for lvl, (a, b) in enumerate(zip(ref, out)):
+                err = float((a - b).abs().max() / a.abs().max())
+                assert 0 < err < 2e-6 or (err == 0 and shape[1] < 0), (shape, lvl, err)   # err > 0: the fused kernel really ran
+            ang = 2 * torch.asin(((gout.double() - gref.double()).norm(dim=-1) / 2).clamp(max=1))
+            assert float(ang.max()) < 1e-5, (shape, float(ang.max()))
+    finally:
+        e.set_option('bottleneck_fused', 1)
+
+
 def test_pointwise_stream_kernel_is_bit_identical(engines):
     """pw_single.hpp (layer2's 1x1 convs and the P2 lateral as a persistent kernel with register-resident weights) against the
     generic contraction kernel: the pyramid must not change by a bit.  The kernel takes over from 64 Ki output pixels: 85 frames of

@@ -296,6 +296,44 @@ def test_every_dma_tile_is_bit_identical(eng, shape):
         assert torch.equal(y.view(torch.int16), outs[9].view(torch.int16)), tile
 
 
+BNECK_TOL = 4e-6   # of the tensor's scale: three chained f16x3 contractions (X3_TOL each) -- measured <= 1.2e-6
+
+
+@pytest.mark.parametrize('nsrc,cn', [(1, 64), (1, 128), (2, 64), (1, 0), (2, 128)])
+@pytest.mark.parametrize('shape', [(3, 56, 56), (2, 28, 84), (1, 9, 5), (2, 30, 37)])
+def test_fused_bottleneck_tail_f16x3(eng, shape, nsrc, cn):
+    """bneck_x3.hpp (conv2 3x3 -> conv3 1x1 (+ downsample source | + residual) -> next conv1 1x1 in one kernel, the three contractions
+    chained in registers) against the f64 statement of the same three layers (resnet.py:263-302), on tile-aligned maps (56x56 = 7 x 2
+    tiles), ragged ones (9x5, 30x37: masked pixels, partial windows) and several frames per launch (persistent grid)."""
+    from mcgaze_amd.packing import bneck_stream
+    N, H, W = shape
+    g = torch.Generator().manual_seed(300 + 7 * nsrc + cn + H)
+    x = torch.randn(N, 64, H, W, generator=g).relu()                      # conv1's output is post-ReLU
+    w2 = torch.randn(64, 64, 3, 3, generator=g) / np.sqrt(576 / 2)
+    b2 = torch.randn(64, generator=g) * 0.1
+    k3 = 64 * nsrc
+    w3 = torch.randn(256, k3, generator=g) / np.sqrt(k3)
+    b3 = torch.randn(256, generator=g) * 0.1
+    src2 = torch.randn(N, 64 if nsrc == 2 else 256, H, W, generator=g).relu()
+    w1n = torch.randn(cn, 256, generator=g) / np.sqrt(128) if cn else None
+    b1n = torch.randn(cn, generator=g) * 0.1 if cn else None
+    t = F.relu(F.conv2d(x.double(), w2.double(), b2.double(), padding=1))
+    a = torch.cat([t, src2.double()], dim=1) if nsrc == 2 else t
+    y = F.conv2d(a, w3.double()[:, :, None, None], b3.double())
+    if nsrc == 1:
+        y = y + src2.double()
+    y = F.relu(y)
+    z = F.relu(F.conv2d(y, w1n.double()[:, :, None, None], b1n.double())) if cn else None
+    ws, bs = bneck_stream(w2.permute(0, 2, 3, 1).contiguous(), b2, w3, b3, w1n, b1n)
+    nhwc = lambda v: v.permute(0, 2, 3, 1).contiguous().to('cuda:0')
+    gy, gz = eng.bottleneck_x3(nhwc(x), nhwc(src2), ws.to('cuda:0'), bs.to('cuda:0'), cn, nsrc)
+    torch.cuda.synchronize()
+    ey = scale_err(gy.permute(0, 3, 1, 2), y.float())
+    ez = scale_err(gz.permute(0, 3, 1, 2), z.float()) if cn else 0.0
+    print(f'fused bottleneck tail {shape} nsrc={nsrc} cn={cn}: y {ey:.2e}, z {ez:.2e} of scale')
+    assert ey < BNECK_TOL and ez < BNECK_TOL, (ey, ez)
+
+
 @pytest.mark.parametrize('shape', [(3, 56, 56), (2, 28, 84), (1, 9, 5), (2, 80, 112)])
 @pytest.mark.parametrize('relu', [True, False])
 def test_conv3x3_c64_is_bit_identical_to_the_generic_kernel(eng, shape, relu):
