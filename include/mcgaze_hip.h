@@ -94,9 +94,11 @@ int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);
 
 /* The fused bottleneck tail as a stand-alone operator (MCG_F16X3 arithmetic; resnet.py:263-302): x = conv2's input
  * [frames][H][W][64] f32; src2 = the residual [frames][H][W][256] (nsrc = 1) or the downsample conv's input [frames][H][W][64]
- * (nsrc = 2); y [..][256]; z [..][cn] (cn = 0: not written).  See mcg_fused_block for wstream / bias. */
+ * (nsrc = 2); y [..][4 cm]; z [..][cn] (cn = 0: not written); cm = 64 or 128 mid channels (x then has cm channels, the residual 4 cm).
+ * trace: NULL, or (measurement aid) a device buffer of 4096 uint64 that workgroup 0 fills with shader-clock stamps of its phases.
+ * See* mcg_fused_block for wstream / bias. */
 int mcg_bottleneck_x3(mcg_stream s, const float* x, const float* src2, const void* wstream, const float* bias, float* y, float* z,
-                      int frames, int H, int W, int nsrc, int cn);
+                      int frames, int H, int W, int cm, int nsrc, int cn, void* trace);
 
 /* Stem: conv 7x7 s2 p3 (3->64) + BN + ReLU then max-pool 3x3 s2 p1 (resnet.py:636-639).
  * img is the reference's NCHW f32 frame tensor.  w_stem is the packed stem weight
@@ -189,8 +191,9 @@ typedef struct {
  * + residual) -> the NEXT block's conv1 (1x1) in one kernel; the 64-channel intermediates never leave the CU and the block output is
  * read from HBM once less.  wstream: the three weight matrices as 16 KiB MFMA-fragment-major slabs of fp16 high / low parts in
  * the order the kernel consumes them (mcgaze_amd/packing.py::bneck_stream gives the exact layout; bytes =
- * 16384 * (9 + 4 * (nsrc + cn / 64))).  bias: f32 [cm | c | cn].  Applies when cm = 64, c = 256, cn in {0, 64, 128} (layer1 of a
- * ResNet-50); other layers keep the layer-granular launches. */
+ * 16384 * (9 (cm / 64)^2 + (cm / 16) (cm / 64 + nsrc - 1 + cn / 64))).  bias: f32 [cm | c | cn].  Applies when cm = 64, c = 256, cn in
+ * {0, 64, 128} (layer1 of a ResNet-50) or cm = 128, c = 512, cn in {0, 128}, nsrc = 1 (layer2's identity blocks); other layers keep
+ * the layer-granular launches. */
 typedef struct {
   const void* wstream;
   const float* bias;

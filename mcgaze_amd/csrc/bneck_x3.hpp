@@ -1,7 +1,8 @@
-// Fused bottleneck tail of the MCG_F16X3 engine (resnet.py:263-302, two consecutive Bottleneck.forward calls), layer1 of a ResNet-50:
+// Fused bottleneck tail of the MCG_F16X3 engine (resnet.py:263-302, two consecutive Bottleneck.forward calls), layer1 (CM = 64 mid
+// channels) and layer2 (CM = 128) of a ResNet-50; C = 4 CM:
 //
-//     t = relu(conv2_3x3(o1) + b2)                         [M][64]    never leaves the CU
-//     y = relu([t | x0] . W3^T + b3 (+ res))               [M][256]   written: the block's output (next residual, C2)
+//     t = relu(conv2_3x3(o1) + b2)                         [M][CM]    never leaves the CU
+//     y = relu([t | x0] . W3^T + b3 (+ res))               [M][C]     written: the block's output (next residual, C2 / C3)
 //     z = relu(y . W1n^T + b1n)                            [M][CN]    written: the NEXT block's conv1 output
 //
 // Layer-granular execution moves, per identity block at f32 activations, 5.76 GB at 448 frames (conv1 reads y, conv2 reads and
@@ -21,7 +22,9 @@
 //     it at one s_barrier per slab (the loader's vmcnt covers its DMA, the barrier publishes it; nothing else orders LDS-DMA);
 //   * a workgroup owns an 8 x 28 pixel tile = 7 groups of 32 pixels = 7 compute waves.  The 10 x 30 x 64 input window of conv2 sits
 //     in LDS split ONCE into fp16 high / low chunk planes (the nine taps are immediates, conv3x3_c64.hpp's layout); the next tile's
-//     window is fetched and parked by the compute waves during the 1x1 phases, when nobody reads the window;
+//     window is fetched and parked by the compute waves during the 1x1 phases, when nobody reads the window.  CM = 128: the planes hold 64
+//     channels at a time -- conv2's K is walked as two halves, the second half's window (prefetched into registers at the start of the
+//     tile) is parked between them behind one extra barrier;
 //   * residual rows and y / z rows move between HBM and registers in the accumulator layout (16-byte pieces, the two lane halves
 //     adjacent: 32 contiguous bytes per pixel row per instruction, a whole 128-byte line per four).
 //
@@ -42,13 +45,15 @@ static_assert(NPIX % 32 == 0, "tile must be whole 32-pixel groups");
 }  // namespace bnx
 
 struct BneckParams {
-  const float* x;        // conv2 input [frames][H][W][64] f32 (the block's conv1 output)
-  const float* res;      // NSRC == 1: residual [M][256];  NSRC == 2: the downsample conv's input [M][64] (block input, stride 1)
+  const float* x;        // conv2 input [frames][H][W][CM] f32 (the block's conv1 output)
+  const float* res;      // NSRC == 1: residual [M][C];  NSRC == 2: the downsample conv's input [M][64] (block input, stride 1)
   const char* wstream;   // weight slabs in consumption order (packing.py::bneck_stream)
-  const float* bias;     // [64 conv2 | 256 conv3 (+ downsample) | CN next conv1]
-  float* y;              // [M][256]
+  const float* bias;     // [CM conv2 | C conv3 (+ downsample) | CN next conv1]
+  float* y;              // [M][C]
   float* z;              // [M][CN] (CN > 0)
   int H, W, tiles_x, tiles_per_frame, total_tiles;
+  unsigned long long* trace;   // optional (measurement aid): workgroup 0 writes s_memtime stamps -- [0..2047] compute wave 0 (tile start, after
+                               // conv2, after each chunk), [2048..4095] the loader wave (each slab's arrival); NULL in the product path
 };
 
 // eight f32 of one lane -> the fp16 high / low B-operand fragments of one K-step
@@ -60,18 +65,48 @@ __device__ __forceinline__ void bnx_split8(const float (&v)[8], bf16x8& hi, bf16
   lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
 }
 
-template <int NSRC, int CN>
+// One K-step of a slab: both channel tiles' weight fragments (high, low) against one pixel fragment (high, low); the six MFMAs
+// alternate between the two accumulators (small terms first) so that no MFMA waits for the one issued just before it.
+__device__ __forceinline__ void bnx_step(const char* sl, const bf16x8& xh, const bf16x8& xl, f32x16& a0, f32x16& a1) {
+  const bf16x8 w0h = __builtin_bit_cast(bf16x8, *(const uint4*)(sl));
+  const bf16x8 w0l = __builtin_bit_cast(bf16x8, *(const uint4*)(sl + 1024));
+  const bf16x8 w1h = __builtin_bit_cast(bf16x8, *(const uint4*)(sl + 8192));
+  const bf16x8 w1l = __builtin_bit_cast(bf16x8, *(const uint4*)(sl + 8192 + 1024));
+  a0 = x3_mfma(w0l, xh, a0);
+  a1 = x3_mfma(w1l, xh, a1);
+  a0 = x3_mfma(w0h, xl, a0);
+  a1 = x3_mfma(w1h, xl, a1);
+  a0 = x3_mfma(w0h, xh, a0);
+  a1 = x3_mfma(w1h, xh, a1);
+}
+
+template <int CM, int NSRC, int CN>
 __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams p) {
   using namespace bnx;
-  constexpr int NS = 9 + 4 * (NSRC + CN / 64);      // slabs per tile
-  constexpr int CT3 = CN / 32;                      // channel tiles of z
+  constexpr int C = 4 * CM, KH = CM / 64, NCH = C / 64;          // output channels, 64-channel K halves of conv2, 64-channel chunks of y
+  constexpr int PARTS = CM / 64 + NSRC - 1;                      // 64-wide K parts of conv3 (t [| second source])
+  constexpr int NS1 = 9 * KH * KH;                               // conv2 slabs: K half x tap x 64-channel output pair
+  constexpr int NS = NS1 + NCH * (PARTS + CN / 64);              // slabs per tile
+  constexpr int CT1 = CM / 32, CT3 = CN / 32;                    // channel tiles of t and z
+  constexpr int WPC = (WIN_ROUNDS + NCH - 1) / NCH;              // window rounds fetched per chunk iteration
+  // residual prefetch depth in 64-channel chunks (32 VGPRs each): what the 256-register budget allows beside the accumulators.  With
+  // one chunk ahead every chunk iteration waited a full (loaded) memory latency for its residual rows -- 15 k cycles per chunk
+  // against 3 k of MFMA work (profiles/r03_g_bneck_phases.md); the 3x3 phase has ~90 free registers to start them under.
+  // The chunk loop stays rolled (fully unrolled, the compiler hoists loads across chunks and spills) and is unrolled by RD only, so the
+  // ring slots are compile-time.
+  // Measured (r03_i): depth 2 moves waiting from the chunk phases into the 3x3 phase and leaves the tile time unchanged (0.933 vs
+  // 0.932 ms) -- the kernel sits at what one CU can pull (~10 B/clk) whenever it touches memory -- so depth 1 and the registers saved.
+  constexpr int RD = 1;
+  static_assert(NCH % RD == 0, "chunk loop is unrolled by the prefetch depth");
+  static_assert(CM == 64 || CM == 128, "64 or 128 mid channels");
+  static_assert(NSRC == 1 || CM == 64, "the second source is layer1's first block only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const s_win = smem;
   char* const s_ring = smem + WIN_BYTES;
   float* const s_bias = (float*)(smem + WIN_BYTES + RING_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 64 + 256 + CN; i += NT) s_bias[i] = p.bias[i];
+  for (int i = tid; i < CM + C + CN; i += NT) s_bias[i] = p.bias[i];
   __syncthreads();
   const int first = blockIdx.x, stride = gridDim.x;
   if (first >= p.total_tiles) return;
@@ -89,11 +124,15 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       slot_issue = slot_issue + 1 == NSLOT ? 0 : slot_issue + 1;
     };
     static_for<NSLOT - 1>([&](auto) { issue(); });
+    int tr_n = 0;
     for (int tile = first; tile < p.total_tiles; tile += stride) {
 #pragma unroll 1
       for (int kt = 0; kt < NS; ++kt) {
+        if (KH == 2 && kt == NS1 / 2) __builtin_amdgcn_s_barrier();                  // the compute waves' window switch (second K half)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * (NSLOT - 2)) : "memory");   // this slab's 16 pieces have landed
+        if (p.trace && blockIdx.x == 0 && lane == 0 && tr_n < 2040) { p.trace[2048 + tr_n] = __builtin_amdgcn_s_memtime(); ++tr_n; }
         __builtin_amdgcn_s_barrier();                                                // published; the previous slab's slot is free
+        if (p.trace && blockIdx.x == 0 && lane == 0 && tr_n < 2040) { p.trace[2048 + tr_n] = __builtin_amdgcn_s_memtime(); ++tr_n; }
         issue();   // always (past the last tile it wraps to slabs nobody reads): the outstanding-piece count stays uniform
       }
     }
@@ -106,8 +145,8 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
   const int m = g * 32 + pl, ty = m / TW, tx = m - ty * TW;
   const char* const bw = s_win + half * 2 * PLANE + (ty * WW + tx) * 16;   // this lane's B-operand base (tap (0,0), K-step 0, high)
   const float* const s_b2 = s_bias;
-  const float* const s_b3 = s_bias + 64;
-  const float* const s_b1 = s_bias + 64 + 256;
+  const float* const s_b3 = s_bias + CM;
+  const float* const s_b1 = s_bias + CM + C;
   const int ctid = tid;                                                       // 0 .. 447 among the compute lanes
 
   auto origin = [&](int t, int& n, int& ty0, int& tx0) {
@@ -116,8 +155,8 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
     ty0 = tyi * TH;
     tx0 = (r - tyi * p.tiles_x) * TW;
   };
-  // window chunk `it` of this lane: 4 consecutive channels (c16) of window pixel wp
-  auto win_load = [&](int t, int it) -> float4 {
+  // window chunk `it` of this lane: 4 consecutive channels (c16) of window pixel wp, K half kh
+  auto win_load = [&](int t, int kh, int it) -> float4 {
     int n, ty0, tx0;
     origin(t, n, ty0, tx0);
     const int idx = it * (NCOMP * 64) + ctid;
@@ -126,7 +165,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
     const int gy = ty0 - 1 + wy, gx = tx0 - 1 + wx;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx < WPIX * 16 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-      v = *(const float4*)(p.x + (((long long)n * p.H + gy) * p.W + gx) * 64 + c16 * 4);
+      v = *(const float4*)(p.x + (((long long)n * p.H + gy) * p.W + gx) * CM + kh * 64 + c16 * 4);
     return v;
   };
   auto win_park = [&](int it, const float4& v) {
@@ -143,31 +182,41 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
   };
 
   // first window
-  for (int it = 0; it < WIN_ROUNDS; ++it) win_park(it, win_load(first, it));
+  for (int it = 0; it < WIN_ROUNDS; ++it) win_park(it, win_load(first, 0, it));
 
   const uint32_t a_lane = (uint32_t)lane * 16u;
   uint32_t slot = 0;                                                          // ring slot of the next slab to consume
   auto slab_ptr = [&]() { return s_ring + slot * SLAB + a_lane; };
   auto slab_next = [&]() { slot = slot + 1 == NSLOT ? 0 : slot + 1; };
 
+  int tr_c = 0;
+  auto stamp = [&]() {
+    if (p.trace && blockIdx.x == 0 && tid == 0 && tr_c < 2040) { p.trace[tr_c] = __builtin_amdgcn_s_memtime(); ++tr_c; }
+  };
   for (int tile = first; tile < p.total_tiles; tile += stride) {
+    stamp();
     int n, ty0, tx0;
     origin(tile, n, ty0, tx0);
     const int gy = ty0 + ty, gx = tx0 + tx;
     const bool valid = gy < p.H && gx < p.W;
+    const bool st_ok = valid, ld_ok = valid;
     const long long row = ((long long)n * p.H + (valid ? gy : 0)) * p.W + (valid ? gx : 0);
     const int next = tile + stride;
     const bool has_next = next < p.total_tiles;
 
     // residual rows of chunk 0 (NSRC == 1) / the second source's fragments (NSRC == 2): in flight under the 3x3 phase
-    float4 rres[2][4];
+    float4 rres[RD][2][4];
     bf16x8 xfh[4], xfl[4];
-    if constexpr (NSRC == 1) {
+    auto res_load = [&](auto slotc, int chunk) {
+      constexpr int SL = decltype(slotc)::value;
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          rres[c][q] = valid ? *(const float4*)(p.res + row * 256 + c * 32 + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+          rres[SL][c][q] = ld_ok ? *(const float4*)(p.res + row * C + chunk * 64 + c * 32 + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if constexpr (NSRC == 1) {
+      static_for<RD>([&](auto d) { res_load(d, decltype(d)::value); });
     } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -178,37 +227,48 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       }
     }
 
-    // ---------------- conv2: 9 tap slabs, K = 64 channels per tap (4 K-steps), both channel tiles of t
-    f32x16 acc1[2];
+    // ---------------- conv2: per K half, per tap, per 64-channel output pair one slab (4 K-steps of 16 channels)
+    float4 w2nd[KH == 2 ? WIN_ROUNDS : 1];                  // CM = 128: the second K half's window, in flight under the first half
+    if constexpr (KH == 2) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+      for (int it = 0; it < WIN_ROUNDS; ++it) w2nd[it] = win_load(tile, 1, it);
+    }
+    f32x16 acc1[CT1];
+#pragma unroll
+    for (int c = 0; c < CT1; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[c][r] = 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's window writes (parked during the previous tile) are done
-    static_for<9>([&](auto tc) {
-      constexpr int TAP = decltype(tc)::value;
-      constexpr int TOFF = ((TAP / 3) * WW + TAP % 3) * 16;
-      __builtin_amdgcn_s_barrier();
-      const char* sl = slab_ptr();
-      static_for<4>([&](auto jc) {
-        constexpr int J = decltype(jc)::value;
-        const bf16x8 xh = __builtin_bit_cast(bf16x8, *(const uint4*)(bw + (4 * J) * PLANE + TOFF));
-        const bf16x8 xl = __builtin_bit_cast(bf16x8, *(const uint4*)(bw + (4 * J + 1) * PLANE + TOFF));
+    static_for<KH>([&](auto khc) {
+      constexpr int KHI = decltype(khc)::value;
+      if constexpr (KHI == 1) {                             // every wave is done with the first half's planes: park the second half
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const bf16x8 wh = __builtin_bit_cast(bf16x8, *(const uint4*)(sl + c * 8192 + J * 2048));
-          const bf16x8 wl = __builtin_bit_cast(bf16x8, *(const uint4*)(sl + c * 8192 + J * 2048 + 1024));
-          acc1[c] = x3_mfma(wl, xh, acc1[c]);
-          acc1[c] = x3_mfma(wh, xl, acc1[c]);
-          acc1[c] = x3_mfma(wh, xh, acc1[c]);
-        }
+        for (int it = 0; it < WIN_ROUNDS; ++it) win_park(it, w2nd[it]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      static_for<9>([&](auto tc) {
+        constexpr int TAP = decltype(tc)::value;
+        constexpr int TOFF = ((TAP / 3) * WW + TAP % 3) * 16;
+        static_for<CM / 64>([&](auto opc) {
+          constexpr int OP = decltype(opc)::value;
+          __builtin_amdgcn_s_barrier();
+          const char* sl = slab_ptr();
+          static_for<4>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, *(const uint4*)(bw + (4 * J) * PLANE + TOFF));
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, *(const uint4*)(bw + (4 * J + 1) * PLANE + TOFF));
+            bnx_step(sl + J * 2048, xh, xl, acc1[2 * OP], acc1[2 * OP + 1]);
+          });
+          slab_next();
+        });
       });
-      slab_next();
     });
-    // t = relu(acc1 + b2) -> B fragments of conv3's four K-steps (K-step s = channels 16 s .. 16 s + 15)
-    bf16x8 tfh[4], tfl[4];
+    stamp();
+    // t = relu(acc1 + b2) -> B fragments of conv3's K-steps (K-step s = channels 16 s .. 16 s + 15)
+    bf16x8 tfh[CM / 16], tfl[CM / 16];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < CM / 16; ++s) {
       const int c = s >> 1, q0 = 2 * (s & 1);
       float v[8];
 #pragma unroll
@@ -229,88 +289,75 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc3[c][r] = 0.f;
 #pragma unroll 1
-    for (int oc = 0; oc < 4; ++oc) {
-      // the next tile's window, three rounds per chunk: loads now, parked after this chunk's contractions
-      float4 wv[3];
+    for (int oc0 = 0; oc0 < NCH; oc0 += RD)
+    static_for<RD>([&](auto occ) {
+      constexpr int SLOT = decltype(occ)::value;
+      const int oc = oc0 + SLOT;
+      // the next tile's window (first K half), WPC rounds per chunk: loads now, parked after this chunk's contractions
+      float4 wv[WPC];
       if (has_next) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          if (oc * 3 + j < WIN_ROUNDS) wv[j] = win_load(next, oc * 3 + j);
+        for (int j = 0; j < WPC; ++j)
+          if (oc * WPC + j < WIN_ROUNDS) wv[j] = win_load(next, 0, oc * WPC + j);
       }
       f32x16 acc2[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[c][r] = 0.f;
-      static_for<NSRC>([&](auto pc) {
+      static_for<PARTS>([&](auto pc) {
         constexpr int PART = decltype(pc)::value;
         __builtin_amdgcn_s_barrier();
         const char* sl = slab_ptr();
         static_for<4>([&](auto sc) {
           constexpr int S = decltype(sc)::value;
-          const bf16x8 bh = PART == 0 ? tfh[S] : xfh[S];
-          const bf16x8 bl = PART == 0 ? tfl[S] : xfl[S];
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, *(const uint4*)(sl + c * 8192 + S * 2048));
-            const bf16x8 wl = __builtin_bit_cast(bf16x8, *(const uint4*)(sl + c * 8192 + S * 2048 + 1024));
-            acc2[c] = x3_mfma(wl, bh, acc2[c]);
-            acc2[c] = x3_mfma(wh, bl, acc2[c]);
-            acc2[c] = x3_mfma(wh, bh, acc2[c]);
-          }
+          const bf16x8 bh = PART < CM / 64 ? tfh[(PART < CM / 64 ? PART : 0) * 4 + S] : xfh[S];
+          const bf16x8 bl = PART < CM / 64 ? tfl[(PART < CM / 64 ? PART : 0) * 4 + S] : xfl[S];
+          bnx_step(sl + S * 2048, bh, bl, acc2[0], acc2[1]);
         });
         slab_next();
       });
-      // y chunk = relu(acc2 + b3 (+ res)); stored; split into the next conv1's B fragments
-      bf16x8 yfh[4], yfl[4];
+      // y chunk = relu(acc2 + b3 (+ res)), finished IN PLACE in the accumulators and stored
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int c = s >> 1, q0 = 2 * (s & 1);
-        float v[8];
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-          const int q = q0 + qq, ch = oc * 64 + c * 32 + 8 * q + 4 * half;
+        for (int q = 0; q < 4; ++q) {
+          const int ch = oc * 64 + c * 32 + 8 * q + 4 * half;
           const float4 b = *(const float4*)(s_b3 + ch);
           float4 o = make_float4(acc2[c][4 * q] + b.x, acc2[c][4 * q + 1] + b.y, acc2[c][4 * q + 2] + b.z, acc2[c][4 * q + 3] + b.w);
-          if constexpr (NSRC == 1) { o.x += rres[c][q].x; o.y += rres[c][q].y; o.z += rres[c][q].z; o.w += rres[c][q].w; }
+          if constexpr (NSRC == 1) { const float4 r = rres[SLOT][c][q]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
           o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-          if (valid) *(float4*)(p.y + row * 256 + ch) = o;
-          v[4 * qq] = o.x; v[4 * qq + 1] = o.y; v[4 * qq + 2] = o.z; v[4 * qq + 3] = o.w;
+          if (st_ok) *(float4*)(p.y + row * C + ch) = o;
+          acc2[c][4 * q] = o.x; acc2[c][4 * q + 1] = o.y; acc2[c][4 * q + 2] = o.z; acc2[c][4 * q + 3] = o.w;
         }
-        if constexpr (CN > 0) bnx_split8(v, yfh[s], yfl[s]);
+      if constexpr (NSRC == 1) {
+        if (oc + RD < NCH) res_load(std::integral_constant<int, SLOT>{}, oc + RD);   // refill the slot just consumed
       }
-      if constexpr (NSRC == 1) {   // the next chunk's residual rows
-        if (oc < 3) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              rres[c][q] = valid ? *(const float4*)(p.res + row * 256 + (oc + 1) * 64 + c * 32 + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-      static_for<CN / 64>([&](auto prc) {
-        constexpr int PR = decltype(prc)::value;
-        __builtin_amdgcn_s_barrier();
-        const char* sl = slab_ptr();
-        static_for<4>([&](auto sc) {
-          constexpr int S = decltype(sc)::value;
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, *(const uint4*)(sl + c * 8192 + S * 2048));
-            const bf16x8 wl = __builtin_bit_cast(bf16x8, *(const uint4*)(sl + c * 8192 + S * 2048 + 1024));
-            acc3[2 * PR + c] = x3_mfma(wl, yfh[S], acc3[2 * PR + c]);
-            acc3[2 * PR + c] = x3_mfma(wh, yfl[S], acc3[2 * PR + c]);
-            acc3[2 * PR + c] = x3_mfma(wh, yfh[S], acc3[2 * PR + c]);
-          }
+      // next conv1: this chunk's 64 channels of y are four K-steps; a step's B fragment is split from the accumulators when it is
+      // needed (per slab: the split is 24 VALU per step, the registers of four fragments would not fit beside 128 output channels)
+      if constexpr (CN > 0) {
+        static_for<CN / 64>([&](auto prc) {
+          constexpr int PR = decltype(prc)::value;
+          __builtin_amdgcn_s_barrier();
+          const char* sl = slab_ptr();
+          static_for<4>([&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            constexpr int YC = S >> 1, R0 = 8 * (S & 1);
+            const float v[8] = {acc2[YC][R0], acc2[YC][R0 + 1], acc2[YC][R0 + 2], acc2[YC][R0 + 3], acc2[YC][R0 + 4], acc2[YC][R0 + 5], acc2[YC][R0 + 6], acc2[YC][R0 + 7]};
+            bf16x8 yh, yl;
+            bnx_split8(v, yh, yl);
+            bnx_step(sl + S * 2048, yh, yl, acc3[2 * PR], acc3[2 * PR + 1]);
+          });
+          slab_next();
         });
-        slab_next();
-      });
+      }
       if (has_next) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          if (oc * 3 + j < WIN_ROUNDS) win_park(oc * 3 + j, wv[j]);
+        for (int j = 0; j < WPC; ++j)
+          if (oc * WPC + j < WIN_ROUNDS) win_park(oc * WPC + j, wv[j]);
       }
-    }
+      stamp();
+    });
     // ---------------- z = relu(acc3 + b1n)
     if constexpr (CN > 0) {
 #pragma unroll
@@ -321,47 +368,52 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
           const float4 b = *(const float4*)(s_b1 + ch);
           const float4 o = make_float4(fmaxf(acc3[c][4 * q] + b.x, 0.f), fmaxf(acc3[c][4 * q + 1] + b.y, 0.f), fmaxf(acc3[c][4 * q + 2] + b.z, 0.f),
                                        fmaxf(acc3[c][4 * q + 3] + b.w, 0.f));
-          if (valid) *(float4*)(p.z + row * CN + ch) = o;
+          if (st_ok) *(float4*)(p.z + row * CN + ch) = o;
         }
     }
   }
 }
 
-// Applicable: layer1 of a ResNet-50 (64 mid channels, 256 out), stride 1, the second source (first block) at stride 1 on the same grid.
+// Applicable: layer1 / layer2 of a ResNet-50 (64 / 128 mid channels, 4 x that out), stride 1; a second source (the first block's
+// downsample input) only for 64 mid channels, 64 channels wide, at stride 1 on the same grid.
 static inline bool bneck_x3_applicable(int cm, int c, int cn, int nsrc, int k2, int stride2) {
-  return cm == 64 && c == 256 && (cn == 0 || cn == 64 || cn == 128) && (nsrc == 1 || (nsrc == 2 && k2 == 64 && stride2 == 1));
+  if (cm == 64) return c == 256 && (cn == 0 || cn == 64 || cn == 128) && (nsrc == 1 || (nsrc == 2 && k2 == 64 && stride2 == 1));
+  return cm == 128 && c == 512 && (cn == 0 || cn == 128) && nsrc == 1;
 }
-static inline size_t bneck_x3_stream_bytes(int nsrc, int cn) { return (size_t)(9 + 4 * (nsrc + cn / 64)) * bnx::SLAB; }
+static inline size_t bneck_x3_stream_bytes(int cm, int nsrc, int cn) {
+  return (size_t)(9 * (cm / 64) * (cm / 64) + (cm / 16) * (cm / 64 + nsrc - 1 + cn / 64)) * bnx::SLAB;
+}
 
-template <int NSRC, int CN>
+template <int CM, int NSRC, int CN>
 static inline int launch_bneck_x3_t(hipStream_t s, const BneckParams& p) {
-  constexpr int kLds = bnx::WIN_BYTES + bnx::RING_BYTES + (64 + 256 + CN) * 4;
+  constexpr int kLds = bnx::WIN_BYTES + bnx::RING_BYTES + (CM + 4 * CM + CN) * 4;
   static int cus_of[MCG_MAX_DEVICES] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
   if (!cus_of[dev]) {
     hipDeviceProp_t prop;
-    if (hipFuncSetAttribute((const void*)bneck_x3_kernel<NSRC, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)bneck_x3_kernel<CM, NSRC, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return 1;
     cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
   const int grid = p.total_tiles < cus_of[dev] ? p.total_tiles : cus_of[dev];
-  hipLaunchKernelGGL((bneck_x3_kernel<NSRC, CN>), dim3(grid), dim3(bnx::NT), kLds, s, p);
+  hipLaunchKernelGGL((bneck_x3_kernel<CM, NSRC, CN>), dim3(grid), dim3(bnx::NT), kLds, s, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 // frames x H x W pixels; returns 0 on success
-static inline int launch_bneck_x3(hipStream_t s, BneckParams p, int frames, int nsrc, int cn) {
+static inline int launch_bneck_x3(hipStream_t s, BneckParams p, int frames, int cm, int nsrc, int cn) {
   const int tiles_y = (p.H + bnx::TH - 1) / bnx::TH;
   p.tiles_x = (p.W + bnx::TW - 1) / bnx::TW;
   p.tiles_per_frame = tiles_y * p.tiles_x;
   const long long total = (long long)p.tiles_per_frame * frames;
   if (total <= 0 || total > 0x7fffffffLL) return 1;
   p.total_tiles = (int)total;
+  if (cm == 128) return cn == 0 ? launch_bneck_x3_t<128, 1, 0>(s, p) : launch_bneck_x3_t<128, 1, 128>(s, p);
   if (nsrc == 1) {
-    if (cn == 0) return launch_bneck_x3_t<1, 0>(s, p);
-    if (cn == 64) return launch_bneck_x3_t<1, 64>(s, p);
-    return launch_bneck_x3_t<1, 128>(s, p);
+    if (cn == 0) return launch_bneck_x3_t<64, 1, 0>(s, p);
+    if (cn == 64) return launch_bneck_x3_t<64, 1, 64>(s, p);
+    return launch_bneck_x3_t<64, 1, 128>(s, p);
   }
-  if (cn == 0) return launch_bneck_x3_t<2, 0>(s, p);
-  if (cn == 64) return launch_bneck_x3_t<2, 64>(s, p);
-  return launch_bneck_x3_t<2, 128>(s, p);
+  if (cn == 0) return launch_bneck_x3_t<64, 2, 0>(s, p);
+  if (cn == 64) return launch_bneck_x3_t<64, 2, 64>(s, p);
+  return launch_bneck_x3_t<64, 2, 128>(s, p);
 }

@@ -49,7 +49,6 @@ struct mcg_engine {
   int trunk_streams = 2;       // concurrent frame ranges of the trunk
   int max_range_frames = 0;    // 0 = what fits the 2 GiB descriptor window
   bool pw_single = true;       // HBM-bound 1x1 convs of layer2 / the P2 lateral (bf16): persistent register-resident-weight kernel (pw_single.hpp)
-  int lab_skip = 0;            // LAB ONLY (timing what-ifs): bits 0-2 = conv1/conv2/conv3, bits 3-6 = layer1..4, bit 7 = laterals, bit 8 = fpn 3x3
   bool pw_pair = true;         // layer1 / layer2 (bf16): conv3 (+ residual) and the next block's conv1 as one kernel (pw_pair.hpp)
   std::mutex mu;               // one forward at a time per engine: the fork/join events and side streams are shared state
 };
@@ -192,7 +191,6 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "decoder_chain")) e->ctx.chain = value != 0;
   else if (!strcmp(name, "pointwise_pair")) e->pw_pair = value != 0;
   else if (!strcmp(name, "pointwise_stream")) e->pw_single = value != 0;
-  else if (!strcmp(name, "lab_skip")) e->lab_skip = value;
   else if (!strcmp(name, "bottleneck_fused")) e->bneck_fused = value != 0;
   else { mcg_set_error("mcg_engine_set_option: unknown option '%s'", name); return MCG_ERR_ARG; }
   return MCG_OK;
@@ -331,12 +329,11 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
       const bool has_ds = b == 0;
       const int ho = (h + 2 * c2.pad - c2.k) / c2.stride + 1, wo = (w + 2 * c2.pad - c2.k) / c2.stride + 1;
       void* y = (b == e->blocks[l] - 1) ? (void*)t.c[l] : (x == t.xa ? (void*)t.xb : (void*)t.xa);
-      const int lsk = (e->lab_skip >> (3 + l)) & 1 ? e->lab_skip & 7 : 0;
-      if (!o1_ready && !(lsk & 1)) MCG_TRY(conv_call(e, s, dt, c1, x, n, h, w, o1, 1, nullptr, MCG_RES_NONE, 0, 0));
+      if (!o1_ready) MCG_TRY(conv_call(e, s, dt, c1, x, n, h, w, o1, 1, nullptr, MCG_RES_NONE, 0, 0));
       o1_ready = false;
       // f16x3: conv2 -> conv3 (+ downsample / + residual) -> the next block's conv1 as ONE kernel (bneck_x3.hpp)
       const mcg_fused_block* fb = nullptr;
-      if (dt == MCG_F16X3 && e->bneck_fused && e->ctx.tile < 0 && !lsk)
+      if (dt == MCG_F16X3 && e->bneck_fused && e->ctx.tile < 0)
         for (const mcg_fused_block& f : e->fused)
           if (f.conv2_index == ci + 1) fb = &f;
       if (fb) {
@@ -353,7 +350,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
           ProfRec* rec = prof_begin(e->ctx, s, 70, n * h * w, fb->c + fb->cn, 9 * fb->cm + fb->cm + k2 + fb->c,
                                     2.0 * M * (9.0 * fb->cm * fb->cm + (double)(fb->cm + k2) * fb->c + (double)fb->c * fb->cn),
                                     4.0 * (M * (fb->cm + (has_ds ? k2 : fb->c) + fb->c + fb->cn) + 9.0 * fb->cm * fb->cm + (double)(fb->cm + k2) * fb->c + (double)fb->c * fb->cn));
-          const int frc = launch_bneck_x3(s, bp, n, fb->nsrc, fb->cn);
+          const int frc = launch_bneck_x3(s, bp, n, fb->cm, fb->nsrc, fb->cn);
           prof_end(rec, s);
           if (frc) { mcg_set_error("bneck_x3 launch failed"); return MCG_ERR_HIP; }
           if (fb->cn > 0) { char* tmp = o1; o1 = o2; o2 = tmp; o1_ready = true; }
@@ -362,8 +359,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
           continue;
         }
       }
-      if (!(lsk & 2)) MCG_TRY(conv_call(e, s, dt, c2, o1, n, h, w, o2, 1, nullptr, MCG_RES_NONE, 0, 0));
-      if (lsk & 4) { x = y; h = ho; w = wo; ci += has_ds ? 4 : 3; continue; }
+      MCG_TRY(conv_call(e, s, dt, c2, o1, n, h, w, o2, 1, nullptr, MCG_RES_NONE, 0, 0));
       // conv3 (+ downsample / + residual) together with the NEXT block's conv1 (pw_pair.hpp): layer1 / layer2, where both are
       // HBM-bound.  The next conv1 is the following block's, or the next layer's first (1x1, stride 1 on this block's output).
       const int ci_next = ci + (has_ds ? 4 : 3);
@@ -418,13 +414,11 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
   int hs[4], wsz[4];
   for (int i = 0; i < 4; ++i) { hs[i] = (H / 4) >> i; wsz[i] = (W / 4) >> i; }
   for (int i = 3; i >= 0; --i) {
-    if (e->lab_skip & 128) break;
     const void* res = i == 3 ? nullptr : t.l[i + 1];
     MCG_TRY(conv_call(e, s, dt, e->lateral[i], t.c[i], n, hs[i], wsz[i], t.l[i], 0, res, res ? MCG_RES_UPSAMPLE_ADD : MCG_RES_NONE,
                       i == 3 ? 0 : hs[i + 1], i == 3 ? 0 : wsz[i + 1]));
   }
   for (int i = 0; i < 4; ++i) {
-    if (e->lab_skip & 256) break;
     char* dst = (char*)pyr[i] + (size_t)f0 * hs[i] * wsz[i] * 256 * es;
     MCG_TRY(conv_call(e, s, dt, e->fpn_out[i], t.l[i], n, hs[i], wsz[i], dst, 0, nullptr, MCG_RES_NONE, 0, 0));
   }
@@ -530,14 +524,14 @@ static int trunk_forward(mcg_engine* e, mcg_stream s_, const float* img, int N, 
 }
 
 extern "C" int mcg_bottleneck_x3(mcg_stream s, const float* x, const float* src2, const void* wstream, const float* bias, float* y, float* z,
-                                 int frames, int H, int W, int nsrc, int cn) {
+                                 int frames, int H, int W, int cm, int nsrc, int cn, void* trace) {
   MCG_CHECK_ARG(x && src2 && wstream && bias && y && (z || cn == 0), "mcg_bottleneck_x3: null pointer");
   MCG_CHECK_ARG(frames > 0 && H > 0 && W > 0, "mcg_bottleneck_x3: empty problem");
-  MCG_CHECK_ARG(bneck_x3_applicable(64, 256, cn, nsrc, 64, 1), "mcg_bottleneck_x3: unsupported shape (nsrc=%d cn=%d)", nsrc, cn);
+  MCG_CHECK_ARG(bneck_x3_applicable(cm, 4 * cm, cn, nsrc, 64, 1), "mcg_bottleneck_x3: unsupported shape (cm=%d nsrc=%d cn=%d)", cm, nsrc, cn);
   BneckParams bp;
   memset(&bp, 0, sizeof(bp));
-  bp.x = x; bp.res = src2; bp.wstream = (const char*)wstream; bp.bias = bias; bp.y = y; bp.z = z; bp.H = H; bp.W = W;
-  if (launch_bneck_x3((hipStream_t)s, bp, frames, nsrc, cn)) { mcg_set_error("mcg_bottleneck_x3: launch failed"); return MCG_ERR_HIP; }
+  bp.x = x; bp.res = src2; bp.wstream = (const char*)wstream; bp.bias = bias; bp.y = y; bp.z = z; bp.H = H; bp.W = W; bp.trace = (unsigned long long*)trace;
+  if (launch_bneck_x3((hipStream_t)s, bp, frames, cm, nsrc, cn)) { mcg_set_error("mcg_bottleneck_x3: launch failed"); return MCG_ERR_HIP; }
   return MCG_OK;
 }
 

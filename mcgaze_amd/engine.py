@@ -88,16 +88,17 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual
     return y
 
 
-def bottleneck_x3(x, src2, wstream, bias, cn, nsrc):
-    """The fused bottleneck tail (mcg_bottleneck_x3): x [N,H,W,64] f32 = conv2's input, src2 = residual [N,H,W,256] (nsrc 1) or the
-    downsample conv's input [N,H,W,64] (nsrc 2); wstream / bias from packing.bneck_stream.  -> (y [N,H,W,256], z [N,H,W,cn] or None)."""
+def bottleneck_x3(x, src2, wstream, bias, cn, nsrc, trace=None):
+    """The fused bottleneck tail (mcg_bottleneck_x3): x [N,H,W,cm] f32 = conv2's input (cm = 64 / 128), src2 = residual [N,H,W,4 cm]
+    (nsrc 1) or the downsample conv's input [N,H,W,64] (nsrc 2); wstream / bias from packing.bneck_stream.
+    -> (y [N,H,W,4 cm], z [N,H,W,cn] or None)."""
     _require_gpu()
     lib = L.load()
-    N, H, W, _ = x.shape
-    y = torch.empty(N, H, W, 256, dtype=torch.float32, device=x.device)
+    N, H, W, cm = x.shape
+    y = torch.empty(N, H, W, 4 * cm, dtype=torch.float32, device=x.device)
     z = torch.empty(N, H, W, cn, dtype=torch.float32, device=x.device) if cn else None
     L.check(lib.mcg_bottleneck_x3(_stream(), _ptr(x.contiguous()), _ptr(src2.contiguous()), _ptr(wstream), _ptr(bias), _ptr(y), _ptr(z),
-                                  N, H, W, nsrc, cn), 'mcg_bottleneck_x3')
+                                  N, H, W, cm, nsrc, cn, _ptr(trace)), 'mcg_bottleneck_x3')
     return y, z
 
 

@@ -99,14 +99,17 @@ def _slab(w64, chain):
 
 def bneck_stream(w2, b2, w3, b3, w1n=None, b1n=None):
     """Weight stream + bias block of one fused bottleneck tail (include/mcgaze_hip.h: mcg_fused_block; bneck_x3.hpp).
-    w2 [64][3][3][64] OHWI, w3 [256][64 (+ 64: the downsample conv's K-concatenated input)], w1n [cn][256] or None -- all f32 with BN
-    folded.  Slab order = consumption order: the 9 taps of w2; then per 64-channel chunk oc of y: w3[oc chunk][K part] for each K
-    part of 64, w1n[64-row pair][oc chunk] for each pair.  -> (fp16 tensor of 8192 halves per slab, f32 bias [64 | 256 | cn])."""
-    assert tuple(w2.shape) == (64, 3, 3, 64) and w3.shape[0] == 256 and w3.shape[1] in (64, 128)
+    w2 [cm][3][3][cm] OHWI (cm = 64 or 128), w3 [4 cm][cm (+ 64: the downsample conv's K-concatenated input, cm = 64 only)], w1n
+    [cn][4 cm] or None -- all f32 with BN folded.  Slab order = consumption order: conv2 per 64-channel K half, per tap, per 64-row
+    output pair; then per 64-channel chunk oc of y: w3[oc chunk][K part] for each K part of 64, w1n[64-row pair][oc chunk] for each
+    pair.  -> (fp16 tensor of 8192 halves per slab, f32 bias [cm | 4 cm | cn])."""
+    cm = w2.shape[0]
+    assert cm in (64, 128) and tuple(w2.shape) == (cm, 3, 3, cm) and w3.shape[0] == 4 * cm and w3.shape[1] in ((64, 128) if cm == 64 else (128,))
     cn = 0 if w1n is None else w1n.shape[0]
-    assert cn in (0, 64, 128) and (w1n is None or w1n.shape[1] == 256)
-    slabs = [_slab(w2[:, kh, kw, :], chain=False) for kh in range(3) for kw in range(3)]
-    for oc in range(4):
+    assert cn % 64 == 0 and cn <= 128 and (w1n is None or w1n.shape[1] == 4 * cm)
+    slabs = [_slab(w2[op * 64:(op + 1) * 64, kh, kw, kk * 64:(kk + 1) * 64], chain=False)
+             for kk in range(cm // 64) for kh in range(3) for kw in range(3) for op in range(cm // 64)]
+    for oc in range(4 * cm // 64):
         for part in range(w3.shape[1] // 64):
             slabs.append(_slab(w3[oc * 64:(oc + 1) * 64, part * 64:(part + 1) * 64], chain=True))
         for pair in range(cn // 64):
@@ -168,26 +171,31 @@ class PackedWeights:
                         wcat = torch.cat([ohwi(w3), ohwi(w)], dim=3)  # [Cout,1,1,planes + inplanes]
                         self.c3_ds.append(dict(w=cmat(wcat), bias=vec(b3 + b), cin=wcat.shape[3], cout=wcat.shape[0], k=1, stride=1, pad=0,
                                                wf=wf1x1(wcat.permute(0, 3, 1, 2))))
-        if split and fuse_downsample:
-            # layer1 (64 mid channels, 256 out, stride 1): every block's conv2 -> conv3 (+ downsample | + residual) -> next conv1
+        if split and fuse_downsample and depth >= 50:
+            # layer1 (64 mid channels; every block, the first with its downsample conv as a second K source) and layer2 (128; the
+            # identity blocks -- the first block's conv2 has stride 2): conv2 -> conv3 (+ downsample | + residual) -> next conv1
             ci = 0
-            for bi in range(self.blocks[0]):
-                has_ds = bi == 0
-                nxt = ci + (4 if has_ds else 3)
-                (w2, b2), (w3, b3) = folded[ci + 1], folded[ci + 2]
-                w3m, b3m = w3.reshape(w3.shape[0], -1), b3
-                if has_ds:
-                    wd, bd = folded[ci + 3]
-                    if self.convs[ci + 3]['stride'] != 1:
-                        break
-                    w3m, b3m = torch.cat([w3m, wd.reshape(wd.shape[0], -1)], dim=1), b3 + bd
-                w1n, b1n = (folded[nxt][0].reshape(folded[nxt][0].shape[0], -1), folded[nxt][1]) if nxt < len(folded) else (None, None)
-                if tuple(w2.shape) != (64, 64, 3, 3) or w3m.shape[0] != 256 or (w1n is not None and (w1n.shape[0] not in (64, 128) or self.convs[nxt]['stride'] != 1)):
-                    break
-                ws, bs = bneck_stream(ohwi(w2), b2, w3m, b3m, w1n, b1n)
-                self.fused.append(dict(wstream=self._dev(ws), bias=self._dev(bs), conv2_index=ci + 1, cm=64, c=256,
-                                       cn=0 if w1n is None else w1n.shape[0], nsrc=2 if has_ds else 1))
-                ci = nxt
+            for li in range(2):
+                cm = 64 << li
+                for bi in range(self.blocks[li]):
+                    has_ds = bi == 0
+                    nxt = ci + (4 if has_ds else 3)
+                    (w2, b2), (w3, b3) = folded[ci + 1], folded[ci + 2]
+                    ok = tuple(w2.shape) == (cm, cm, 3, 3) and self.convs[ci + 1]['stride'] == 1 and w3.shape[0] == 4 * cm and not (has_ds and li > 0)
+                    if ok:
+                        w3m, b3m = w3.reshape(w3.shape[0], -1), b3
+                        if has_ds:
+                            wd, bd = folded[ci + 3]
+                            ok = self.convs[ci + 3]['stride'] == 1 and wd.shape[1] == 64
+                            w3m, b3m = torch.cat([w3m, wd.reshape(wd.shape[0], -1)], dim=1), b3 + bd
+                    if ok:
+                        w1n = b1n = None
+                        if nxt < len(folded) and self.convs[nxt]['k'] == 1 and self.convs[nxt]['stride'] == 1 and self.convs[nxt]['cout'] in ((64, 128) if cm == 64 else (128,)):
+                            w1n, b1n = folded[nxt][0].reshape(folded[nxt][0].shape[0], -1), folded[nxt][1]
+                        ws, bs = bneck_stream(ohwi(w2), b2, w3m, b3m, w1n, b1n)
+                        self.fused.append(dict(wstream=self._dev(ws), bias=self._dev(bs), conv2_index=ci + 1, cm=cm, c=4 * cm,
+                                               cn=0 if w1n is None else w1n.shape[0], nsrc=2 if has_ds else 1))
+                    ci = nxt
         self.lateral, self.fpn_out = [], []
         for i in range(4):
             w = sd[f'neck.lateral_convs.{i}.conv.weight']

@@ -299,9 +299,9 @@ def test_every_dma_tile_is_bit_identical(eng, shape):
 BNECK_TOL = 4e-6   # of the tensor's scale: three chained f16x3 contractions (X3_TOL each) -- measured <= 1.2e-6
 
 
-@pytest.mark.parametrize('nsrc,cn', [(1, 64), (1, 128), (2, 64), (1, 0), (2, 128)])
-@pytest.mark.parametrize('shape', [(3, 56, 56), (2, 28, 84), (1, 9, 5), (2, 30, 37)])
-def test_fused_bottleneck_tail_f16x3(eng, shape, nsrc, cn):
+@pytest.mark.parametrize('cm,nsrc,cn', [(64, 1, 64), (64, 1, 128), (64, 2, 64), (64, 1, 0), (64, 2, 128), (128, 1, 128), (128, 1, 0)])
+@pytest.mark.parametrize('shape', [(3, 56, 56), (2, 28, 84), (1, 9, 5), (2, 30, 37), (5, 28, 28)])
+def test_fused_bottleneck_tail_f16x3(eng, shape, cm, nsrc, cn):
     """bneck_x3.hpp (conv2 3x3 -> conv3 1x1 (+ downsample source | + residual) -> next conv1 1x1 in one kernel, the three contractions
     chained in registers) against the f64 statement of the same three layers (resnet.py:263-302), on tile-aligned maps (56x56 = 7 x 2
     tiles), ragged ones (9x5, 30x37: masked pixels, partial windows) and several frames per launch (persistent grid)."""
