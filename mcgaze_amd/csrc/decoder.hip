@@ -6,6 +6,7 @@
 #include "attn_block.hpp"
 #include "pw_single.hpp"
 #include "igemm_dma.hpp"
+#include "chain_x3.hpp"
 
 #include <string.h>
 
@@ -246,144 +247,6 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const T* __restrict__ roi,
   }
 }
 
-// The same DynamicConv core in the MCG_F16X3 arithmetic (f32 storage; every product as three fp16 MFMAs on the operands' fp16 high / low
-// parts, f32 accumulate -- igemm_dma.hpp's contraction).  The f32 engine's kernel above runs its 8.4 MFLOP per token on the f32 MFMA
-// (1/16 of the fp16 rate: 72 us of matrix-pipe time per 1344 tokens at peak, 112 us measured); here a K-step is 16 channels, both
-// operand fragments (eight f32 each, straight from L2) are split in registers, and F1 goes through LDS already split.
-__global__ __launch_bounds__(256) void dynconv_x3_kernel(const float* __restrict__ roi, const float* __restrict__ params,
-                                                         const float* __restrict__ g_in, const float* __restrict__ b_in,
-                                                         const float* __restrict__ g_out, const float* __restrict__ b_out, float* __restrict__ out) {
-  constexpr int P = 49, DI = 256, DF = 64;
-  constexpr int D1_LD = DF + 4, D2_LD = DI + 4;
-  constexpr int A2_ROWB = 256;                            // F1 row as stage 2's A operand: 4 K-steps x 2 lane halves x (high, low) x 16 B
-  constexpr int A2_BYTES = 64 * A2_ROWB, D1_BYTES = 64 * D1_LD * 4, D2_BYTES = P * D2_LD * 4;
-  constexpr int LDS_BYTES = D2_BYTES > D1_BYTES + A2_BYTES ? D2_BYTES : D1_BYTES + A2_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-  float* D1 = (float*)smem;
-  float* D2 = (float*)smem;
-  char* A2 = smem + D1_BYTES;
-  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-  const float* __restrict__ F = roi + (long long)r * P * DI;
-  const float* __restrict__ Win = params + (long long)r * (2 * DI * DF);
-  const float* __restrict__ Wout = Win + DI * DF;
-  auto frag = [](const float* p8, bool ok, bf16x8& hi, bf16x8& lo) {   // eight consecutive f32 -> fp16 high / low fragments
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    split_f32x8(ok ? *(const uint4*)p8 : z, ok ? *(const uint4*)(p8 + 4) : z, hi, lo);
-  };
-  // ---- stage 1: wave -> one 32x32 tile of D1[64][64], K = 256 = 16 steps
-  {
-    const int tm = wave >> 1, tn = wave & 1;
-    const int prow = tm * 32 + (lane & 31), ncol = tn * 32 + (lane & 31);
-    const bool pv = prow < P;
-    const float* ap = F + (long long)prow * DI + half * 8;
-    const float* bp = Win + (long long)ncol * DI + half * 8;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 4
-    for (int s = 0; s < DI / 16; ++s) {
-      bf16x8 ah, al, bh, bl;
-      frag(ap + 16 * s, pv, ah, al);
-      frag(bp + 16 * s, true, bh, bl);
-      acc = x3_mfma(al, bh, acc);
-      acc = x3_mfma(ah, bl, acc);
-      acc = x3_mfma(ah, bh, acc);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) D1[(tm * 32 + mfma32_row(i, lane)) * D1_LD + tn * 32 + (lane & 31)] = acc[i];
-  }
-  // stage 2's weight fragments (wave -> columns [wave*64, +64) of Wout^T, K = 64 = 4 steps): raw f32, in flight across the LayerNorm
-  uint4 wraw[4][2][2];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const float* wp = Wout + (long long)(wave * 64 + b * 32 + (lane & 31)) * DF + 16 * s + 8 * half;
-      wraw[s][b][0] = *(const uint4*)wp;
-      wraw[s][b][1] = *(const uint4*)(wp + 4);
-    }
-  __syncthreads();
-  // ---- LN over 64 features + ReLU, one wave per row, lane = feature; F1 is parked as stage 2's A operand, split into fp16 high / low
-  for (int row = wave; row < 64; row += 4) {
-    float v = D1[row * D1_LD + lane];
-    const float mean = wave_sum(v) * (1.0f / DF);
-    const float d = v - mean;
-    const float rstd = 1.0f / sqrtf(wave_sum(d * d) * (1.0f / DF) + 1e-5f);
-    v = fmaxf(d * rstd * g_in[lane] + b_in[lane], 0.f);
-    const float vn = dpp_mov<0xB1>(v, 0.f);              // quad_perm [1,0,3,2]: the neighbouring feature
-    if (!(lane & 1)) {
-      uint32_t h, l;
-      split_pair(v, vn, h, l);
-      const int s = lane >> 4, hf = (lane >> 3) & 1, pos = (lane & 7) >> 1;   // K-step, lane half of the consumer, 4-byte slot
-      char* dst = A2 + row * A2_ROWB + (((s * 4 + hf * 2) ^ (row & 15)) << 4) + pos * 4;
-      *(uint32_t*)dst = h;
-      *(uint32_t*)(A2 + row * A2_ROWB + (((s * 4 + hf * 2 + 1) ^ (row & 15)) << 4) + pos * 4) = l;
-    }
-  }
-  __syncthreads();  // D1 fully consumed, A2 complete
-  // ---- stage 2: wave -> columns [wave*64, +64) of D2[64][256], 2x2 tiles, K = 64
-  {
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int row = a * 32 + (lane & 31);
-        ah[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(A2 + row * A2_ROWB + (((s * 4 + half * 2) ^ (row & 15)) << 4)));
-        al[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(A2 + row * A2_ROWB + (((s * 4 + half * 2 + 1) ^ (row & 15)) << 4)));
-      }
-#pragma unroll
-      for (int b = 0; b < 2; ++b) split_f32x8(wraw[s][b][0], wraw[s][b][1], bh[b], bl[b]);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = x3_mfma(al[a], bh[b], acc[a][b]);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = x3_mfma(ah[a], bl[b], acc[a][b]);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = x3_mfma(ah[a], bh[b], acc[a][b]);
-    }
-    __syncthreads();  // every wave is done reading A2 before D2 (which aliases it) is written
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = a * 32 + mfma32_row(i, lane);
-          if (row < P) D2[row * D2_LD + wave * 64 + b * 32 + (lane & 31)] = acc[a][b][i];
-        }
-  }
-  __syncthreads();
-  // ---- LN over 256 channels + ReLU, one wave per position, lane owns 4 consecutive channels
-  for (int row = wave; row < P; row += 4) {
-    const float4 t = *(const float4*)(D2 + row * D2_LD + lane * 4);
-    float v[4] = {t.x, t.y, t.z, t.w};
-    const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / DI);
-    float q = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] -= mean; q += v[e] * v[e]; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / DI) + 1e-5f);
-    float4 o;
-    o.x = fmaxf(v[0] * rstd * g_out[lane * 4] + b_out[lane * 4], 0.f);
-    o.y = fmaxf(v[1] * rstd * g_out[lane * 4 + 1] + b_out[lane * 4 + 1], 0.f);
-    o.z = fmaxf(v[2] * rstd * g_out[lane * 4 + 2] + b_out[lane * 4 + 2], 0.f);
-    o.w = fmaxf(v[3] * rstd * g_out[lane * 4 + 3] + b_out[lane * 4 + 3], 0.f);
-    *(float4*)(out + ((long long)r * P + row) * DI + lane * 4) = o;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Per-clue score / box heads + delta2bbox (gaze_stqi_head.py:191-201, delta_xywh_bbox_coder.py:224-260),
 // one wave per token; token r uses clue r % 3's weights.
@@ -559,6 +422,7 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
   const void* xin = obj_in;
   char* xout[2] = {w.x1, w.x2};
   const bool chain_attn = bf && ctx.chain;
+  const bool chain_x3 = dt == MCG_F16X3 && ctx.chain;   // f16x3: the row-block chains in the split arithmetic (chain_x3.hpp)
   const bool block_attn = chain_attn && attn_block_applicable(clip_length);
   if (block_attn) {  // both passes, one launch, one clip per workgroup (attn_block.hpp); bit-identical to the loop below
     AttnBlockParams ap;
@@ -573,13 +437,13 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
     if (bf) launch_attn<bf16_t>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
     else launch_attn<float>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
     MCG_CHECK_LAUNCH("attn_core");
-    if (chain_attn) {  // out_proj + residual + LayerNorm as one launch
+    if (chain_attn || chain_x3) {  // out_proj + residual + LayerNorm as one launch
       ChainParams cp;
       memset(&cp, 0, sizeof(cp));
       cp.x = w.att; cp.M = R; cp.steps = 1;
       cp.st[0].W = W[MCG_SW_OUT_PROJ_WF]; cp.st[0].bias = f32w[MCG_SW_OUT_PROJ_B]; cp.st[0].res = xin;
       cp.st[0].g = f32w[MCG_SW_ATTN_LN_G]; cp.st[0].b = f32w[MCG_SW_ATTN_LN_B]; cp.st[0].dst = xout[pass]; cp.st[0].from_input = 1;
-      if (launch_mlp_chain(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
+      if (chain_x3 ? launch_mlp_chain_x3(s, cp) : launch_mlp_chain(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
     } else {
       MCG_TRY(launch_linear(s, dt, w.att, 256, W[MCG_SW_OUT_PROJ_W], f32w[MCG_SW_OUT_PROJ_B], xin, 256, w.t, 256, R, 256, 256, 0, ctx));
       MCG_TRY(launch_ln(s, dt, ln_simple(w.t, f32w[MCG_SW_ATTN_LN_G], f32w[MCG_SW_ATTN_LN_B], 0, xout[pass], R, 256)));
@@ -600,7 +464,6 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
     MCG_TRY(launch_linear(s, dt, w.x2, 256, W[MCG_SW_DYN_W], f32w[MCG_SW_DYN_B], nullptr, 0, w.params, 32768, R, 256, 32768, 0, ctx));
   }
   if (bf) hipLaunchKernelGGL(dynconv_kernel<bf16_t>, dim3(R), dim3(256), 0, s, (const bf16_t*)roi_feat, (const bf16_t*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (bf16_t*)w.feat2);
-  else if (dt == MCG_F16X3 && ctx.chain) hipLaunchKernelGGL(dynconv_x3_kernel, dim3(R), dim3(256), 0, s, (const float*)roi_feat, (const float*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (float*)w.feat2);
   else hipLaunchKernelGGL(dynconv_kernel<float>, dim3(R), dim3(256), 0, s, (const float*)roi_feat, (const float*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (float*)w.feat2);
   MCG_CHECK_LAUNCH("dynconv");
   int slabs = 1;
@@ -629,8 +492,8 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
   }
   // --- towers (gaze_stqi_head.py:185-188)
   const void* rin = obj_out;
-  const bool chain = bf && ctx.chain;
-  if (chain) {  // cls tower + 3-layer reg tower: eight launches as one (chain.hpp), bit-identical
+  const bool chain = (bf || dt == MCG_F16X3) && ctx.chain;
+  if (chain) {  // cls tower + 3-layer reg tower: eight launches as one (chain.hpp: bit-identical; f16x3: chain_x3.hpp)
     ChainParams cp;
     memset(&cp, 0, sizeof(cp));
     cp.x = obj_out; cp.M = R; cp.steps = 4;
@@ -642,7 +505,7 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
       st.g = f32w[MCG_SW_REG_LN_G] + j * 256; st.b = f32w[MCG_SW_REG_LN_B] + j * 256;
       st.from_input = j == 0; st.relu = 1; st.dst = j == 2 ? w.r1 : nullptr;
     }
-    if (launch_mlp_chain(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
+    if (bf ? launch_mlp_chain(s, cp) : launch_mlp_chain_x3(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
     rin = w.r1;
   } else {
     MCG_TRY(launch_linear(s, dt, obj_out, 256, W[MCG_SW_CLS_FC_W], nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0, ctx));

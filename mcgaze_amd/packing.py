@@ -60,6 +60,19 @@ def frag_major(w):
     return v.contiguous().reshape(*lead, rows, K)
 
 
+def frag_major_split(w):
+    """f32 [..., 32 nt out, 16 nk in] -> the MFMA-fragment-major SPLIT copy chain_x3.hpp reads: fp16 [..., t = nt][ks = nk][high, low][lane = 64][e = 8]
+    with element (t, ks, hl, lane, e) = the fp16 high (hl = 0) / low part of W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e]; 4 bytes
+    per weight, one wave-wide 16-byte load per (tile, K-step, part) is 1 KiB contiguous."""
+    w = w.float()
+    hi = w.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (w - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    lead = w.shape[:-2]
+    rows, K = w.shape[-2:]
+    fh, fl = frag_major(hi).reshape(*lead, rows // 32, K // 16, 64, 8), frag_major(lo).reshape(*lead, rows // 32, K // 16, 64, 8)
+    return torch.stack([fh, fl], dim=-3).reshape(*lead, rows, 2 * K).contiguous()
+
+
 def split_pack(w):
     """f32 [..., K] -> fp16 [..., 2K], the weight operand of the MCG_F16X3 contraction (include/mcgaze_hip.h): per 8 consecutive
     K elements a 16-byte chunk of fp16 high parts, then a 16-byte chunk of fp16 low parts; hi = f16(w), lo = f16(w - hi), so
@@ -230,8 +243,15 @@ class PackedWeights:
                 HEAD_CLS_B=vec(torch.cat([sd[p + f'.{c}_fc_cls.bias'] for c in CLUES])),
                 HEAD_REG_W=vec(torch.stack([sd[p + f'.{c}_fc_reg.weight'] for c in CLUES])),
                 HEAD_REG_B=vec(torch.stack([sd[p + f'.{c}_fc_reg.bias'] for c in CLUES])))
-            for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W', 'IN_PROJ_W', 'DYN_W'):   # fragment-major copies for the fused chain / attention-block kernels (bf16 engine only)
-                st[k + 'F'] = frag_major(st[k]) if dtype == torch.bfloat16 else st[k]
+            raw = dict(OUT_PROJ_W=sd[p + '.attention.attn.out_proj.weight'], CLS_FC_W=sd[p + '.cls_fcs.0.weight'],
+                       REG_FC_W=torch.stack([sd[p + f'.reg_fcs.{3 * j}.weight'] for j in range(3)]))
+            for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W', 'IN_PROJ_W', 'DYN_W'):   # fragment-major copies for the fused chain / attention-block kernels
+                if dtype == torch.bfloat16:
+                    st[k + 'F'] = frag_major(st[k])
+                elif split and k in raw:
+                    st[k + 'F'] = self._dev(frag_major_split(raw[k]))              # f16x3: the chains' split fragment-major operands (chain_x3.hpp)
+                else:
+                    st[k + 'F'] = st[k]
             assert st['HEAD_CLS_W'].shape == (3, 256), 'use_sigmoid=True heads expected (gaze_stqi_head.py:72-75)'
             self.stages.append(st)
         # only the LAST stage's gaze head runs at inference (multiclue_gaze_roi_head.py:367,378)

@@ -1,11 +1,12 @@
-"""GPU tool: decoder-only (4 x [RoIAlign + stage] + gaze head) step time on precomputed pyramids.  Usage: python tools/decoder_time.py [iters]"""
+"""GPU tool: decoder-only (4 x [RoIAlign + stage] + gaze head) step time on precomputed pyramids.  Usage: python tools/decoder_time.py [iters] [precision=bf16]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mcgaze_amd import lib as L, synth
 from mcgaze_amd.engine import HipEngine, _ptr, _ws, _stream
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-e = HipEngine(synth.make_state_dict(0), precision='bf16')
+prec = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
+e = HipEngine(synth.make_state_dict(0), precision=prec)
 img = torch.from_numpy(synth.make_clips(3, 64, 7)).cuda()
 N, T, H, W = img.shape[0], 7, 224, 224
 pyr = e.backbone_fpn(img)
@@ -17,4 +18,4 @@ def run():
 for _ in range(5): run()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(iters): run()
-torch.cuda.synchronize(); print(f'decoder only: {(time.perf_counter() - t0) / iters * 1e3:.3f} ms/step')
+torch.cuda.synchronize(); print(f'decoder only ({prec}): {(time.perf_counter() - t0) / iters * 1e3:.3f} ms/step')

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 240 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o $C --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel-events none --pipeline 0 --trunk-streams 1 --parity-engine ${PARITY:-none} --latency 0 --precision ${PRECISION:-bf16} > $OUT/$C.log 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o $C --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel-events none --pipeline 0 --trunk-streams 1 --second-engine none --latency 0 --mae-videos 0 --backbone-clips 0 --precision ${PRECISION:-f16x3} > $OUT/$C.log 2>&1
   echo "$C pass rc=$?"
 done
 cd $R
@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob(f'{out}/{sub}/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
-            if 'igemm' in row['Kernel_Name'] or 'pw_pair' in row['Kernel_Name'] or 'pw_single' in row['Kernel_Name']:
+            if any(k in row['Kernel_Name'] for k in ('igemm', 'pw_pair', 'pw_single', 'bneck_x3')):
                 agg[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
 res = {}
 for k, d in agg.items():
@@ -24,6 +24,8 @@ for k, d in agg.items():
     m = re.search(r'igemm_dma_kernel<float, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 1>', k)
     if m:
         name = f'igemm_dma_kernel<float,{",".join(m.groups())},x3>'
+    if 'bneck_x3' in k:
+        name = 'bneck_x3_kernel (conv2 3x3 + conv3 + next conv1, layer1 / layer2 tails)'
     if 'pw_pair' in k:
         name = 'pw_pair_kernel (conv3 + next conv1, layer1)'
     if 'pw_single' in k:
@@ -37,6 +39,9 @@ for k, e in res.items():   # several instantiations may share one reported name:
     e['fetch_bytes_per_launch'] = round(e.pop('fetch_total') / n); e['write_bytes_per_launch'] = round(e.pop('write_total') / n)
     e['hbm_bytes_per_launch'] = e['fetch_bytes_per_launch'] + e['write_bytes_per_launch']
     e['note'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, averaged over the launches of this symbol in bench.py steps; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (HBM section); L2-miss traffic, Infinity-Cache hits included'
-json.dump(res, open(f'{out}/../pmc_traffic.json', 'w'), indent=1)
+import os
+prev = json.load(open(f'{out}/../pmc_traffic.json')) if os.path.exists(f'{out}/../pmc_traffic.json') else {}
+prev.update(res)
+json.dump(prev, open(f'{out}/../pmc_traffic.json', 'w'), indent=1)
 print(json.dumps(res, indent=1))
 PY
