@@ -571,6 +571,8 @@ def main():
         del leg.runner
         leg.runner = None
         sleg, second, second_back = run_engine(a.second_engine, a.second_steps or a.steps, max(2, a.warmup))
+        if second.get('roofline'):
+            second['roofline'].pop('launches', None)       # the per-launch listing is the headline engine's
         second = dict({'dtype': a.second_engine, 'what': WHAT[a.second_engine],
                        'oracle': 'oracle/mcgaze_oracle.py (fp32 CPU restatement pinned to the reference goldens) on clip 0 of this batch'}, **second)
         engines_for_mae[a.second_engine] = sleg.eng

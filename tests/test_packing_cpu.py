@@ -1,0 +1,120 @@
+"""CPU: the weight layouts the round-3 kernels read (bneck_x3.hpp's slab stream, chain_x3.hpp's split fragment-major matrices) against
+their index formulas restated element by element, the fused-tail table PackedWeights builds, and bench.py's roofline bookkeeping."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from mcgaze_amd import packing, synth
+
+
+def _parts(w):
+    hi = w.float().to(torch.float16)
+    lo = (w.float() - hi.float()).to(torch.float16)
+    return hi, lo
+
+
+def test_split_halves_reconstruct_to_22_bits():
+    """hi + lo = w to 2^-22 relative while the low half is a normal fp16 (|w| >= 0.125); below, the low half is subnormal and the
+    error is absolute: 2^-25 (include/mcgaze_hip.h MCG_F16X3)."""
+    w = torch.randn(64, 64) * 0.7
+    hi, lo = _parts(w)
+    err = ((hi.double() + lo.double()) - w.double()).abs()
+    big = w.abs() >= 0.125
+    assert float((err / w.double().abs().clamp_min(1e-30))[big].max()) <= 2.0 ** -22
+    assert float(err[~big].max()) <= 2.0 ** -25
+
+
+def test_bneck_slab_layout_matches_the_kernel_formulas():
+    """packing._slab: [2 channel tiles][4 K-steps][high, low][64 lanes][8]; natural K order for conv2 (the B operand comes from the window
+    planes), the chain permutation 16 s + 4 (lane >> 5) + (e & 3) + 8 (e >> 2) for conv3 / next conv1 (the B operand is the previous
+    contraction's accumulators: channels {0..3, 8..11} + 4 half of a K-step) -- bneck_x3.hpp."""
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(64, 64, generator=g)
+    hi, lo = _parts(w)
+    for chain in (False, True):
+        sl = packing._slab(w, chain)
+        assert tuple(sl.shape) == (2, 4, 2, 64, 8) and sl.dtype == torch.float16
+        rs = np.random.RandomState(1)
+        for _ in range(400):
+            ct, s, hl, lane, e = (int(rs.randint(n)) for n in (2, 4, 2, 64, 8))
+            row, half = 32 * ct + (lane & 31), lane >> 5
+            col = 16 * s + (4 * half + (e & 3) + 8 * (e >> 2) if chain else 8 * half + e)
+            assert sl[ct, s, hl, lane, e] == (hi, lo)[hl][row, col]
+        cols = sorted({16 * s + (4 * h + (e & 3) + 8 * (e >> 2) if chain else 8 * h + e) for s in range(4) for h in range(2) for e in range(8)})
+        assert cols == list(range(64))          # every K index exactly once: a permutation inside each K-step
+
+
+def test_bneck_stream_order_and_sizes():
+    """Slab order = consumption order (include/mcgaze_hip.h mcg_fused_block): conv2 per K half / tap / output pair, then per 64-channel
+    chunk of y the conv3 parts and the next conv1's pairs; 16 KiB per slab; bias [cm | 4 cm | cn]."""
+    g = torch.Generator().manual_seed(6)
+    for cm, k2, cn in ((64, 0, 64), (64, 64, 128), (64, 0, 0), (128, 0, 128), (128, 0, 0)):
+        w2 = torch.randn(cm, 3, 3, cm, generator=g)
+        w3 = torch.randn(4 * cm, cm + k2, generator=g)
+        w1 = torch.randn(cn, 4 * cm, generator=g) if cn else None
+        b = [torch.randn(n, generator=g) for n in (cm, 4 * cm, cn)]
+        ws, bs = packing.bneck_stream(w2, b[0], w3, b[1], w1, b[2] if cn else None)
+        nslab = 9 * (cm // 64) ** 2 + (cm // 16) * ((cm + k2) // 64 + cn // 64)
+        assert ws.numel() == nslab * 8192 and ws.dtype == torch.float16 and bs.numel() == 5 * cm + cn
+        ws = ws.reshape(nslab, 2, 4, 2, 64, 8)
+        # conv2: slab index ((kk * 9 + tap) * pairs + op)
+        pairs = cm // 64
+        kk, tap, op = pairs - 1, 5, pairs - 1
+        want = packing._slab(w2[op * 64:(op + 1) * 64, tap // 3, tap % 3, kk * 64:(kk + 1) * 64], chain=False)
+        assert torch.equal(ws[(kk * 9 + tap) * pairs + op], want)
+        # chunk oc: parts of w3, then pairs of w1
+        per = (cm + k2) // 64 + cn // 64
+        oc = 4 * cm // 64 - 1
+        base = 9 * pairs * pairs + oc * per
+        part = (cm + k2) // 64 - 1
+        assert torch.equal(ws[base + part], packing._slab(w3[oc * 64:(oc + 1) * 64, part * 64:(part + 1) * 64], chain=True))
+        if cn:
+            pr = cn // 64 - 1
+            assert torch.equal(ws[base + (cm + k2) // 64 + pr], packing._slab(w1[pr * 64:(pr + 1) * 64, oc * 64:(oc + 1) * 64], chain=True))
+        assert torch.equal(bs, torch.cat([b[0], b[1]] + ([b[2]] if cn else [])))
+
+
+def test_frag_major_split_layout():
+    g = torch.Generator().manual_seed(7)
+    w = torch.randn(3, 256, 256, generator=g)
+    f = packing.frag_major_split(w)
+    assert tuple(f.shape) == (3, 256, 512) and f.dtype == torch.float16
+    f = f.reshape(3, 8, 16, 2, 64, 8)
+    hi, lo = _parts(w)
+    rs = np.random.RandomState(2)
+    for _ in range(400):
+        m, t, ks, hl, lane, e = (int(rs.randint(n)) for n in (3, 8, 16, 2, 64, 8))
+        assert f[m, t, ks, hl, lane, e] == (hi, lo)[hl][m, 32 * t + (lane & 31), 16 * ks + 8 * (lane >> 5) + e]
+
+
+def test_packed_weights_fused_tail_table():
+    """f16x3: layer1's three blocks (the first with its downsample conv as second K source) and layer2's identity blocks; next conv1
+    fused where its width fits (64 / 128); none for the other engines."""
+    sd = synth.make_state_dict(0)
+    w = packing.PackedWeights(sd, dtype=torch.float32, device='cpu', split=True)
+    got = [(f['conv2_index'], f['cm'], f['c'], f['cn'], f['nsrc']) for f in w.fused]
+    assert got == [(1, 64, 256, 64, 2), (5, 64, 256, 64, 1), (8, 64, 256, 128, 1), (15, 128, 512, 128, 1), (18, 128, 512, 128, 1), (21, 128, 512, 0, 1)]
+    for f in w.fused:
+        nslab = 9 * (f['cm'] // 64) ** 2 + (f['cm'] // 16) * (f['cm'] // 64 + f['nsrc'] - 1 + f['cn'] // 64)
+        assert f['wstream'].numel() == nslab * 8192 and f['bias'].numel() == 5 * f['cm'] + f['cn']
+        c2 = w.convs[f['conv2_index']]
+        assert c2['k'] == 3 and c2['stride'] == 1 and c2['cin'] == f['cm']
+    assert packing.PackedWeights(sd, dtype=torch.bfloat16, device='cpu').fused == []
+    assert packing.PackedWeights(sd, dtype=torch.float32, device='cpu').fused == []
+    st = w.stages[0]
+    assert st['OUT_PROJ_WF'].dtype == torch.float16 and tuple(st['REG_FC_WF'].shape) == (3, 256, 512)
+
+
+def test_bench_roofline_bookkeeping():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    rec = [(0.5, 1.0e11, 50, (1000, 256, 2304), 2.0e8), (0.25, 0.5e11, 50, (1000, 256, 2304), 1.0e8), (0.1, 1.0e9, 51, (100, 256, 256), 1.0e6),
+           (0.9, 2.0e11, 70, (5000, 320, 896), 3.6e9)]
+    r = bench.roofline_of(rec, 'f16x3')
+    assert r['kernel'] == bench.CFG_NAMES[70] and r['launches_per_step'] == 1          # dominant = the largest total time
+    assert abs(r['achieved'] - 2.0e11 / 0.9e-3 / 1e12) < 0.01 and r['algorithmic_bytes_per_launch'] == int(3.6e9)
+    assert len(r['launches']) == 4 and r['launches'][0][:4] == [50, 1000, 256, 2304] and r['algorithmic_bytes_step'] == int(2.0e8 + 1.0e8 + 1.0e6 + 3.6e9)
+    assert 'three fp16 MFMAs' in r['note']
