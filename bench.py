@@ -91,6 +91,7 @@ def parse():
                     help='1: two-deep batch pipeline (decoder of step k overlaps trunk of step k+1 on a second stream; '
                          'every batch is fully processed inside the timed region), 0: one stream, strictly serial')
     ap.add_argument('--trunk-streams', type=int, default=2, help='concurrent frame ranges of the trunk (engine option)')
+    ap.add_argument('--decoder-priority', type=int, default=-1, help='HIP stream priority of the batch pipeline\'s decoder stream (-1 = high: the default; 0 = the trunk\'s)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the cpu_baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--latency', type=int, default=1, choices=[0, 1], help='1: report single-clip latency (rank 0, N=1 only)')
     ap.add_argument('--kernel-events', default='sample', choices=['sample', 'none'],
@@ -184,7 +185,7 @@ class Leg:
         self.eng.set_option('trunk_streams', a.trunk_streams)
         self.gathers = [ResultGather(self.N, world, dev) for _ in range(2)]   # results double-buffered like the pipeline
         self.outs = [g.local_views() for g in self.gathers]                    # the engine writes straight into the fused exchange buffers
-        self.runner = PipelinedRunner(self.eng, self.N, a.size, a.size, T, a.chunk_frames) if a.pipeline and self.workload == 'full' else None
+        self.runner = PipelinedRunner(self.eng, self.N, a.size, a.size, T, a.chunk_frames, decoder_priority=a.decoder_priority) if a.pipeline and self.workload == 'full' else None
         # The result exchange runs on its own stream, ordered only after the decoder that produced the slot: on the caller's stream
         # it would sit between successive submits and serialise batch k+1's trunk behind batch k's decoder (the pipeline's whole point).
         self.comm = comm_stream(dev) if dist is not None else None

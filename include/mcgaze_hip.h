@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 9
+#define MCG_ABI_VERSION 10
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
 /* MCG_F16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
@@ -306,6 +306,9 @@ int mcg_engine_profile_stop(mcg_engine* e, int* count, float* ms, double* flops,
 /* BASELINE.json configs[1] "R-50 backbone-only": stem + layer1..4 (C2..C5 stay in the workspace), no FPN.  Not a product entry
  * point; ws >= mcg_trunk_workspace_bytes(e, num_frames, H, W, 0). */
 int mcg_bench_backbone_forward(mcg_engine* e, mcg_stream s, const float* img, int num_frames, int H, int W, void* ws, size_t ws_bytes);
+/* Where that call left C2..C5 (NHWC [num_frames][H/4 >> i][W/4 >> i][256 << i], engine dtype) inside ws, for a batch that ran as ONE
+ * frame range (engine option trunk_streams = 1): tests/test_gpu_forward.py::test_backbone_only_matches_the_oracle. */
+int mcg_bench_backbone_levels(const mcg_engine* e, void* ws, int num_frames, int H, int W, void* levels[4]);
 
 #ifdef __cplusplus
 }

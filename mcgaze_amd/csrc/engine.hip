@@ -545,6 +545,17 @@ extern "C" int mcg_bench_backbone_forward(mcg_engine* e, mcg_stream s, const flo
   return trunk_forward(e, s, img, N, H, W, 0, nullptr, ws, ws_bytes, true);
 }
 
+// Where mcg_bench_backbone_forward left C2..C5 (NHWC, engine dtype) for a batch that ran as ONE frame range (trunk_streams = 1, or fewer
+// than 112 frames): pointers into the caller's workspace.  Test / measurement aid.
+extern "C" int mcg_bench_backbone_levels(const mcg_engine* e, void* ws, int N, int H, int W, void* levels[4]) {
+  MCG_CHECK_ARG(e && ws && levels, "mcg_bench_backbone_levels: null pointer");
+  MCG_TRY(check_shape(N, H, W));
+  MCG_CHECK_ARG(trunk_ranges(e, N) == 1 && N <= range_frame_cap(e, H, W), "mcg_bench_backbone_levels: the batch runs as several frame ranges (set trunk_streams = 1)");
+  const TrunkWs t = trunk_layout(e->dt, N, H, W, (char*)ws);
+  for (int i = 0; i < 4; ++i) levels[i] = t.c[i];
+  return MCG_OK;
+}
+
 extern "C" int mcg_decoder_forward(mcg_engine* e, mcg_stream s_, const void* const pyramid[4], int N, int clip_length, int H, int W,
                                    const int* img_hw, float* gaze_out, float* boxes_out, float* scores_out, void* ws, size_t ws_bytes) {
   hipStream_t s = (hipStream_t)s_;

@@ -226,13 +226,26 @@ class HipEngine:
         L.check(self.lib.mcg_engine_profile_stop(self._handle, C.byref(cnt), ms, fl, by, cf, sh, capacity), 'mcg_engine_profile_stop')
         return [(ms[i], fl[i], cf[i], (sh[3 * i], sh[3 * i + 1], sh[3 * i + 2]), by[i]) for i in range(cnt.value)]
 
-    def backbone_only(self, img):
-        """BASELINE.json configs[1] measurement: the trunk up to C5 (mcg_bench_backbone_forward); returns nothing."""
+    def backbone_only(self, img, return_levels=False):
+        """BASELINE.json configs[1] measurement: the trunk up to C5 (mcg_bench_backbone_forward).  return_levels: C2..C5 as NHWC views
+        into the engine's workspace (valid until the next call; needs the batch to run as one frame range: set_option('trunk_streams', 1))."""
         self._check_img(img)
         N, _, H, W = img.shape
         with torch.cuda.device(self.device):
             ws = self._workspace(N, H, W, 0)
             L.check(self.lib.mcg_bench_backbone_forward(self._handle, _stream(self.device), _ptr(img), N, H, W, _ptr(ws), ws.numel()), 'mcg_bench_backbone_forward')
+            if not return_levels:
+                return None
+            tab = (C.c_void_p * 4)()
+            L.check(self.lib.mcg_bench_backbone_levels(self._handle, _ptr(ws), N, H, W, tab), 'mcg_bench_backbone_levels')
+            es = ws.element_size() * (2 if self.dtype == torch.bfloat16 else 4)
+            out = []
+            for i in range(4):
+                shape = (N, (H // 4) >> i, (W // 4) >> i, 256 << i)
+                n = shape[0] * shape[1] * shape[2] * shape[3]
+                off = tab[i] - ws.data_ptr()
+                out.append(ws[off:off + n * es].view(self.dtype).view(shape))
+            return out
 
     def __del__(self):
         h = getattr(self, '_handle', None)

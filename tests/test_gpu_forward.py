@@ -395,6 +395,34 @@ def test_pointwise_pair_fusion_is_bit_identical(engines):
         e.set_option('pointwise_pair', 1)
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'bf16'])
+def test_backbone_only_matches_the_oracle(engines, precision):
+    """BASELINE.json configs[1] -- R-50 backbone only, 32 clips x 7 frames x 3 x 224 x 224 -- through mcg_bench_backbone_forward
+    (`bench.py`'s `backbone` sub-object times exactly this call): C2..C5 against oracle.resnet on the same 224 frames.  f16x3 within 2e-5
+    of each level's scale (the parity engine; fused bottleneck tails included), bf16 within 6 % (bound test: 8-bit mantissas over 50
+    layers); and the call leaves the engine usable (a full forward afterwards reproduces itself bit for bit)."""
+    e = engines[precision]
+    B, T = 32, 7
+    img = synth.make_clips(21, B, T)
+    x = torch.from_numpy(img).to('cuda:0')
+    before = {k: v.clone() for k, v in e.forward(x[:T].contiguous(), T).items()}
+    torch.set_num_threads(16)
+    want = orc.resnet(orc.as_torch(synth.make_state_dict(0)), torch.from_numpy(img))
+    e.set_option('trunk_streams', 1)
+    try:
+        got = e.backbone_only(x, return_levels=True)
+        torch.cuda.synchronize()
+        for i, (g, w) in enumerate(zip(got, want)):
+            err = float((g.float().permute(0, 3, 1, 2).cpu() - w).abs().max() / w.abs().max())
+            print(f'backbone only, {precision}, C{i + 2}: max error {err:.2e} of scale')
+            assert err < (2e-5 if precision == 'f16x3' else 6e-2), (precision, i, err)
+    finally:
+        e.set_option('trunk_streams', 2)
+    after = e.forward(x[:T].contiguous(), T)
+    torch.cuda.synchronize()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+
+
 def test_fused_bottleneck_tails_match_the_layer_granular_trunk(engines):
     """The f16x3 engine with layer1 through bneck_x3.hpp (default) against the same engine with the layer-granular launches
     (`bottleneck_fused` = 0).  Not bit-identical by construction -- the chained contractions visit the 16 channels of a K-step in a
