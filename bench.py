@@ -62,6 +62,7 @@ CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,
              61: 'pw_single_kernel (HBM-bound 1x1 convs, register-resident weights)', 62: 'pw_single_kernel<16,2,0,128> (dynamic_layer)',
              # f16x3 contraction (f32 activations, split-packed weights, 3 fp16 MFMAs per product)
              70: 'bneck_x3_kernel (conv2 3x3 + conv3 + next conv1, layer1 / layer2 tails)',
+             71: 'pw_single_x3_kernel (HBM-bound 256 -> 256 / 1024 convs, register-resident split weights)',
              50: 'igemm_dma_kernel<float,256,256,128,4,2,2,2,x3>', 51: 'igemm_dma_kernel<float,128,128,128,2,2,2,2,x3>', 52: 'igemm_dma_kernel<float,256,64,128,4,1,2,2,x3>'}
 
 

@@ -11,6 +11,7 @@
 #include "pw_pair.hpp"
 #include "pw_single.hpp"
 #include "bneck_x3.hpp"
+#include "pw_single_x3.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -307,6 +308,22 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
     const int prc = launch_pw_single(s, pp, cw.cin, cw.cout, rm == MCG_RES_NONE ? 0 : (rm == MCG_RES_ADD ? 1 : 2));
     prof_end(rec, s);
     if (prc) { mcg_set_error("pw_single launch failed"); return MCG_ERR_HIP; }
+    return MCG_OK;
+  }
+  if (dt == MCG_F16X3 && e->pw_single && e->ctx.tile < 0 && cw.wf && cw.bias && cw.k == 1 && cw.stride == 1 && cw.pad == 0 &&
+      pw_single_x3_applicable(cw.cin, cw.cout, rm, M, rm == MCG_RES_UPSAMPLE_ADD ? (long long)n * hr * wr : M) && M < 0x7fffffffll) {
+    // f16x3: the HBM-bound 256 -> 256 / 256 -> 1024 convs by the persistent streaming kernel (pw_single_x3.hpp)
+    PwSingleParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.a = x; pp.res = res; pp.wf = cw.wf; pp.bias = cw.bias; pp.y = y;
+    pp.M = (int)M; pp.relu = relu; pp.Ho = h; pp.Wo = w;
+    if (rm == MCG_RES_UPSAMPLE_ADD) { pp.Hr = hr; pp.Wr = wr; pp.rscale_h = (float)hr / (float)h; pp.rscale_w = (float)wr / (float)w; }
+    const double res_rows = rm == MCG_RES_NONE ? 0.0 : (rm == MCG_RES_ADD ? (double)M : (double)n * hr * wr);
+    ProfRec* rec = prof_begin(e->ctx, s, 71, pp.M, cw.cout, cw.cin, 2.0 * M * cw.cin * cw.cout,
+                              4.0 * ((double)M * (cw.cin + cw.cout) + res_rows * cw.cout + (double)cw.cin * cw.cout));
+    const int prc = launch_pw_single_x3(s, pp, cw.cout, rm == MCG_RES_NONE ? 0 : (rm == MCG_RES_ADD ? 1 : 2));
+    prof_end(rec, s);
+    if (prc) { mcg_set_error("pw_single_x3 launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
   }
   return conv2d_ctx(s, dt, &d, e->ctx);

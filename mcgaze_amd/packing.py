@@ -157,7 +157,12 @@ class PackedWeights:
         cmat = (lambda t: self._dev(split_pack(t.reshape(t.shape[0], -1)))) if split else mat                      # OHWI conv weight
         vec = lambda t: self._dev(t.float())
         # fragment-major copies of the 1x1 convs (bf16 engine): operands of the register-resident-weight kernels (pw_pair.hpp, pw_single.hpp)
-        wf1x1 = (lambda w: self._dev(frag_major(w.reshape(w.shape[0], -1).to(dtype)))) if dtype == torch.bfloat16 else (lambda w: None)
+        if dtype == torch.bfloat16:
+            wf1x1 = lambda w: self._dev(frag_major(w.reshape(w.shape[0], -1).to(dtype)))
+        elif split:   # f16x3: split fragment-major copies for the shapes pw_single_x3.hpp serves (256 -> 256 / 1024)
+            wf1x1 = lambda w: (self._dev(frag_major_split(w.reshape(w.shape[0], -1))) if (w.shape[1] == 256 and w.shape[0] in (256, 1024) and w.reshape(w.shape[0], -1).shape[1] == 256) else None)
+        else:
+            wf1x1 = lambda w: None
 
         w, b = fold_bn(sd, 'backbone.conv1.weight', 'backbone.bn1')
         stem = torch.zeros(64, 7, 8, 4)

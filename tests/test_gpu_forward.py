@@ -474,6 +474,25 @@ FUZZ_CROSSED_CLIP_BOUND = 0.05                 # rad, gaze-vector angle inside a
 _fuzz_seen = {}
 
 
+def test_pointwise_stream_x3_matches_the_contraction_kernel(engines):
+    """pw_single_x3.hpp (f16x3: the P2 lateral and layer3's conv3 as a persistent kernel with register-resident split weights) against the
+    generic x3 contraction kernel: same K order, term order and rounding points -- the pyramid must not change by a bit.  The kernel takes
+    over from 64 Ki output pixels: 22 frames of 224 x 256 reach only the lateral (ragged tile count), 340 frames bring in layer3."""
+    e = engines['f16x3']
+    try:
+        for shape in ((22, 224, 256), (96, 224, 224), (340, 224, 224)):
+            img = torch.from_numpy(synth.make_clips(67, 1, *shape)).to('cuda:0')
+            e.set_option('pointwise_stream', 0)
+            ref = [p.clone() for p in e.backbone_fpn(img)]
+            e.set_option('pointwise_stream', 1)
+            out = e.backbone_fpn(img)
+            torch.cuda.synchronize()
+            for lvl, (a, b) in enumerate(zip(ref, out)):
+                assert torch.equal(a, b), (shape, lvl, float((a - b).abs().max()))
+    finally:
+        e.set_option('pointwise_stream', 1)
+
+
 @pytest.mark.parametrize('index', range(FUZZ_CASES))
 def test_parity_on_random_shapes_and_weights(engines_by_weights, index):
     """tools/parity_fuzz.py's cases 0..15 of seed 2 (random clip length, batch, frame size, img_shape inside the padded frame, three

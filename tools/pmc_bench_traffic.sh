@@ -24,11 +24,13 @@ for k, d in agg.items():
     m = re.search(r'igemm_dma_kernel<float, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 1>', k)
     if m:
         name = f'igemm_dma_kernel<float,{",".join(m.groups())},x3>'
+    if 'pw_single_x3' in k:
+        name = 'pw_single_x3_kernel (HBM-bound 256 -> 256 / 1024 convs, register-resident split weights)'
     if 'bneck_x3' in k:
         name = 'bneck_x3_kernel (conv2 3x3 + conv3 + next conv1, layer1 / layer2 tails)'
     if 'pw_pair' in k:
         name = 'pw_pair_kernel (conv3 + next conv1, layer1)'
-    if 'pw_single' in k:
+    if 'pw_single' in k and 'pw_single_x3' not in k:
         name = 'pw_single_kernel<16,2,0,128> (dynamic_layer)' if re.search(r'pw_single_kernel<16, 2, 0, 128>', k) else 'pw_single_kernel (HBM-bound 1x1 convs, register-resident weights)'
     e = res.setdefault(name, {'fetch_total': 0.0, 'write_total': 0.0, 'launches_sampled': 0})
     e['fetch_total'] += sum(d['FETCH_SIZE']) * 1024 * 2   # KiB units; x2: gfx950 FETCH_SIZE counts 128-B requests as 64 B
