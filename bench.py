@@ -63,6 +63,7 @@ CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,
              # f16x3 contraction (f32 activations, split-packed weights, 3 fp16 MFMAs per product)
              70: 'bneck_x3_kernel (conv2 3x3 + conv3 + next conv1, layer1 / layer2 tails)',
              71: 'pw_single_x3_kernel (HBM-bound 256 -> 256 / 1024 convs, register-resident split weights)',
+             72: 'pw_single_x3_kernel<16,0,256> (dynamic_layer)',
              50: 'igemm_dma_kernel<float,256,256,128,4,2,2,2,x3>', 51: 'igemm_dma_kernel<float,128,128,128,2,2,2,2,x3>', 52: 'igemm_dma_kernel<float,256,64,128,4,1,2,2,x3>'}
 
 
@@ -349,7 +350,7 @@ def oracle_clip0(img_np, T, size):
 
 def deviation(out, want_yp, T):
     from oracle import mcgaze_oracle as orc
-    return float((orc.yaw_pitch(out['gaze'][0][:T].float().cpu()) - want_yp).abs().max())
+    return float(orc.wrap_yaw(orc.yaw_pitch(out['gaze'][0][:T].float().cpu()) - want_yp).abs().max())
 
 
 def single_clip_latency(precisions, dev, T, size, iters=60):

@@ -7,6 +7,7 @@
 #include "pw_single.hpp"
 #include "igemm_dma.hpp"
 #include "chain_x3.hpp"
+#include "pw_single_x3.hpp"
 
 #include <string.h>
 
@@ -460,6 +461,15 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
     const int rc = launch_pw_dyn(s, pp);
     prof_end(rec, s);
     if (rc) { mcg_set_error("pw_single (dynamic_layer) launch failed"); return MCG_ERR_HIP; }
+  } else if (chain_x3 && ctx.tile < 0 && pw_dyn_applicable(R) && (long long)R * 1024 < MCG_DMA_MAX_BYTES) {
+    // f16x3: the same with split weights, 256 slices of 128 columns (pw_single_x3.hpp); bit-identical to the x3 contraction kernel
+    PwSingleParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.a = w.x2; pp.wf = W[MCG_SW_DYN_WF]; pp.bias = f32w[MCG_SW_DYN_B]; pp.y = w.params; pp.M = R; pp.Ho = 1; pp.Wo = 1;
+    ProfRec* rec = prof_begin(ctx, s, 72, R, 32768, 256, 2.0 * R * 32768 * 256, 4.0 * ((double)R * (256 + 32768) + 32768.0 * 256));
+    const int rc = launch_pw_dyn_x3(s, pp);
+    prof_end(rec, s);
+    if (rc) { mcg_set_error("pw_single_x3 (dynamic_layer) launch failed"); return MCG_ERR_HIP; }
   } else {
     MCG_TRY(launch_linear(s, dt, w.x2, 256, W[MCG_SW_DYN_W], f32w[MCG_SW_DYN_B], nullptr, 0, w.params, 32768, R, 256, 32768, 0, ctx));
   }

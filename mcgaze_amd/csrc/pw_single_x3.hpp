@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256, 2) void pw_single_x3_kernel(const PwSinglePara
   const int tid = threadIdx.x, lane = tid & 63, px = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bid = blockIdx.x, nwalkers = gridDim.x / NSPLIT;
-  const int nsp = (bid >> 3) % NSPLIT, walker = (bid / (8 * NSPLIT)) * 8 + (bid & 7);   // ids 8 apart sit on the same XCD
+  // ids 8 apart sit on the same XCD; many_slices (dynamic_layer: 256 slices): workgroup id = walker * NSPLIT + slice
+  const int nsp = p.many_slices ? bid % NSPLIT : (bid >> 3) % NSPLIT, walker = p.many_slices ? bid / NSPLIT : (bid / (8 * NSPLIT)) * 8 + (bid & 7);
   float4 breg[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) breg[q] = *(const float4*)(p.bias + nsp * N + wave * 32 + 8 * q + 4 * half);
@@ -153,5 +154,27 @@ static inline int launch_pw_single_x3(hipStream_t s, const PwSingleParams& p, in
     else if (res_mode == 1) launch_pw_single_x3_t<16, 1, 8>(s, p);
     else launch_pw_single_x3_t<16, 2, 8>(s, p);
   }
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// DynamicConv's `dynamic_layer` for the f16x3 engine (transformer.py:1131-1134): y[M][32768] = x[M][256] . W^T + b on M = 1344 tokens,
+// 176 MB of f32 output: 256 slices of 128 columns, each slice's split weights resident in the registers of two workgroups that share
+// the token tiles (pw_single.hpp's launch_pw_dyn).  Bit-identical to the x3 contraction kernel.
+static inline int launch_pw_dyn_x3(hipStream_t s, PwSingleParams p) {
+  constexpr int KS = 16, NSPLIT = 256, kLds = 32 * 512 + 32 * 64 * KS;
+  static int cus_of[MCG_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
+  if (!cus_of[dev]) {
+    hipDeviceProp_t prop;
+    (void)hipFuncSetAttribute((const void*)pw_single_x3_kernel<KS, 0, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  const int ntiles = (p.M + 31) / 32;
+  int walkers = 2 * cus_of[dev] / NSPLIT;                       // two workgroups per CU
+  if (walkers < 1) walkers = 1;
+  if (walkers > ntiles) walkers = ntiles;
+  p.many_slices = 1;
+  hipLaunchKernelGGL((pw_single_x3_kernel<KS, 0, NSPLIT>), dim3(walkers * NSPLIT), dim3(256), kLds, s, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -329,6 +329,20 @@ def forward(sd, img, img_metas, clip_length, rescale=False, depth=50, collect=No
         return torch.cat([boxes, scores], dim=-1), gaze
 
 
+def wrap_yaw(d):
+    """A (yaw, pitch) DIFFERENCE with its yaw component taken modulo 2 pi into (-pi, pi]: yaw = atan2(x, -z) has its branch cut where
+    the gaze points straight back, and two vectors 1e-5 rad apart on either side of it differ by 2 pi in the raw subtraction
+    (tools/parity_fuzz.py, seed 11 case 891)."""
+    d = d.clone()
+    d[..., 0] = torch.remainder(d[..., 0] + math.pi, 2 * math.pi) - math.pi
+    return d
+
+
+def yaw_pitch_diff(a, b):
+    """|(yaw, pitch)(a) - (yaw, pitch)(b)| per component, yaw wrapped: the quantity north_star bounds by 1e-3."""
+    return wrap_yaw(yaw_pitch(a) - yaw_pitch(b)).abs()
+
+
 def yaw_pitch(g):
     """(yaw, pitch) = (atan2(x, -z), asin(y)) -- the comparison domain north_star names
     (yaw definition: tools/calculate_mae_gaze360.py:60-74)."""

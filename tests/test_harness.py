@@ -239,7 +239,7 @@ def test_dataset_run_matches_the_cpu_oracle_end_to_end(tmp_path):
     for rec, ref in zip(recs, want):
         got, exp = torch.tensor(rec['fusion_gazes']), torch.tensor(ref['fusion_gazes'])
         assert got.shape == exp.shape
-        assert float((orc.yaw_pitch(got) - orc.yaw_pitch(exp)).abs().max()) < 1e-3
+        assert float(orc.yaw_pitch_diff(got, exp).max()) < 1e-3
         for c in ('face', 'eyes', 'head'):
             assert float((torch.tensor(rec[f'{c}_gazes']) - torch.tensor(ref[f'{c}_gazes'])).abs().max()) < 1e-3
             assert np.allclose(np.array(rec[f'{c}_score']), np.array(ref[f'{c}_score']), atol=1e-3)

@@ -38,7 +38,7 @@ def test_forward_matches_reference_golden(golden_dir, weights, name):
     for k in ('gaze_score', 'face_gaze_score', 'eyes_gaze_score', 'head_gaze_score'):
         np.testing.assert_allclose(gaze[k].numpy(), g[k], atol=2e-5, rtol=0)
     # north_star tolerance domain: (yaw, pitch) within 1e-3 -- the oracle sits at ~1e-6
-    assert (orc.yaw_pitch(gaze['gaze_score']) - orc.yaw_pitch(g['gaze_score'])).abs().max() < 1e-4
+    assert orc.yaw_pitch_diff(gaze['gaze_score'], g['gaze_score']).max() < 1e-4
     np.testing.assert_allclose(det.numpy(), g['det_bboxes'], atol=5e-3, rtol=1e-5)
     for s, c in enumerate(col):
         np.testing.assert_allclose(c['obj'].numpy(), g['stage_obj'][s], atol=1e-4, rtol=0)
@@ -136,3 +136,16 @@ def test_roi_align_independent_pins():
             assert abs(float(got[ph, pw]) - v) < 1e-5, ((ph, pw), float(got[ph, pw]), v)
     boxes = torch.tensor([b for b, _ in P.LEVEL_EDGE_BOXES])
     assert orc.map_roi_levels(boxes).tolist() == [l for _, l in P.LEVEL_EDGE_BOXES]
+
+
+def test_yaw_difference_is_taken_modulo_two_pi():
+    """yaw = atan2(x, -z) has its branch cut where the gaze points straight back: two vectors 1e-5 rad apart on either side of it differ by
+    2 pi in a raw subtraction (tools/parity_fuzz.py seed 11 case 891).  orc.yaw_pitch_diff wraps the yaw difference into (-pi, pi]."""
+    import math
+    a = torch.tensor([[1e-5, 0.3, 1.0], [0.2, 0.1, -1.0]])
+    b = torch.tensor([[-1e-5, 0.3, 1.0], [0.2, 0.1, -1.0]])
+    a, b = a / a.norm(dim=1, keepdim=True), b / b.norm(dim=1, keepdim=True)
+    raw = (orc.yaw_pitch(a) - orc.yaw_pitch(b)).abs()
+    assert abs(float(raw[0, 0]) - 2 * math.pi) < 1e-4                      # the artefact
+    d = orc.yaw_pitch_diff(a, b)
+    assert float(d.max()) < 3e-5 and float(d[1].max()) == 0.0

@@ -47,7 +47,7 @@ base = float(metric.compute_angular_error(ref, gt))
 for name in ('bf16', 'fp16'):
     g = out[name]
     ang = 2 * torch.asin(((g.double() - ref.double()).norm(dim=-1) / 2).clamp(max=1))
-    d = (orc.yaw_pitch(g) - orc.yaw_pitch(ref)).abs().max(dim=1).values
+    d = orc.yaw_pitch_diff(g, ref).max(dim=1).values
     sh = float(metric.compute_angular_error(g, gt)) - base
     per_clip = d.reshape(clips, T).max(dim=1).values
     print(f'{name}: angle vs fp32 oracle median {float(ang.median()):.2e} mean {float(torch.rad2deg(ang).mean()):.3f} deg max {float(ang.max()):.2e} rad; '

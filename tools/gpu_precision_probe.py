@@ -28,7 +28,7 @@ def decoder(pyr, p):
     return E.gaze_head(w.gaze, obj)[0].cpu()
 
 def report(name, gz):
-    d = (orc.yaw_pitch(gz) - orc.yaw_pitch(ref)).abs()
+    d = orc.yaw_pitch_diff(gz, ref)
     ang = torch.rad2deg(torch.acos((gz * ref).sum(-1).clamp(-1, 1)))
     print(f'{name:32s} max|d(yaw,pitch)| {d.max():.2e} rad   mean ang err {ang.mean():.3f} deg  max {ang.max():.3f}')
 

@@ -38,7 +38,7 @@ for c in range(cases):
             engines[key] = HipEngine(sds[wseed], precision=p)
         hw = None if full else np.tile(np.array([ih, iw], dtype=np.int32), (N, 1))
         out = engines[key].forward(torch.from_numpy(img).cuda(), T, img_hw=hw)
-        d = float((orc.yaw_pitch(out['gaze'][0].cpu()) - want).abs().max())
+        d = float(orc.wrap_yaw(orc.yaw_pitch(out['gaze'][0].cpu()) - want).abs().max())
         worst[p] = max(worst[p], d)
         ang = float((2 * torch.asin(((out['gaze'][0].cpu().double() - ref['gaze_score'].double()).norm(dim=-1) / 2).clamp(max=1))).max())
         devs.append(f'{d:.2e} / {ang:.2e}')
@@ -49,7 +49,7 @@ for c in range(cases):
         elif d > 1e-3:
             rep = PT.stage_report(engines[key], p, sds[wseed], img, metas, T, stages)
             note, disc = f'{p}: ' + PT.describe(rep), rep['discontinuity']
-            err = orc.yaw_pitch(out['gaze'][0].cpu()) - want
+            err = orc.wrap_yaw(orc.yaw_pitch(out['gaze'][0].cpu()) - want)
             f = int(err.abs().max(dim=1).values.argmax())
             gy = float(ref['gaze_score'][f, 1])
             vec = float((out['gaze'][0].cpu()[f] - ref['gaze_score'][f]).norm())
