@@ -89,13 +89,10 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
   constexpr int NS = NS1 + NCH * (PARTS + CN / 64);              // slabs per tile
   constexpr int CT1 = CM / 32, CT3 = CN / 32;                    // channel tiles of t and z
   constexpr int WPC = (WIN_ROUNDS + NCH - 1) / NCH;              // window rounds fetched per chunk iteration
-  // residual prefetch depth in 64-channel chunks (32 VGPRs each): what the 256-register budget allows beside the accumulators.  With
-  // one chunk ahead every chunk iteration waited a full (loaded) memory latency for its residual rows -- 15 k cycles per chunk
-  // against 3 k of MFMA work (profiles/r03_g_bneck_phases.md); the 3x3 phase has ~90 free registers to start them under.
-  // The chunk loop stays rolled (fully unrolled, the compiler hoists loads across chunks and spills) and is unrolled by RD only, so the
-  // ring slots are compile-time.
-  // Measured (r03_i): depth 2 moves waiting from the chunk phases into the 3x3 phase and leaves the tile time unchanged (0.933 vs
-  // 0.932 ms) -- the kernel sits at what one CU can pull (~10 B/clk) whenever it touches memory -- so depth 1 and the registers saved.
+  // Residual prefetch depth in 64-channel chunks (32 VGPRs each); the chunk loop is unrolled by RD only, so the ring slots are
+  // compile-time (fully unrolled, the compiler hoists loads across chunks and spills).  Measured (profiles/r03_g_bneck_phases.md): depth 2
+  // moves the waiting from the 1x1 phases into the 3x3 phase and leaves the tile time where it was (0.933 vs 0.932 ms, + 22 registers):
+  // whenever the kernel touches memory it runs at what one CU can pull.  Depth 1.
   constexpr int RD = 1;
   static_assert(NCH % RD == 0, "chunk loop is unrolled by the prefetch depth");
   static_assert(CM == 64 || CM == 128, "64 or 128 mid channels");
