@@ -87,7 +87,7 @@ typedef struct {
    * resnet.py:289-298): x2 = the block input, w2 = the BN-folded downsample weight. */
   const void* x2;       /* NHWC [N,H2,W2,Cin2] or NULL */
   int Cin2, stride2, H2, W2;
-  int tile;             /* 0 = heuristic; else force this tile id of the contraction kernel (igemm.hip: 9, 11, 12, 14, 15; f16x3: 50, 51) */
+  int tile;             /* 0 = heuristic; else force this tile id of the contraction kernel (igemm.hip: 9, 11, 12, 14, 15; f16x3: 50, 51, 53) */
   int flags;            /* MCG_FLAG_* */
 } mcg_conv_desc;
 int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);

@@ -161,6 +161,13 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups, const M
 //   50 = 256x256 8 waves (64x128 wave tiles: the A split is shared by four column tiles), 2 stages, 128 KiB -- deep, wide layers
 //   51 = 128x128 4 waves, 2 stages, 64 KiB (two workgroups per CU) -- Cout < 256, few rows (7x7 maps, decoder linears)
 //   52 = 256x64 4 waves -- Cout <= 64
+//   53 = 128x128 with EIGHT waves (32 x 64 wave tiles) and a four-stage ring (128 KiB) -- grids of at most one workgroup per CU with a
+//        deep K (a single clip: M = 1372 rows in layer3, 343 in layer4; K = 1024 .. 4608).  There a K step of tile 51 is one wave per
+//        SIMD doing its DMA wait, its A split and its MFMAs in sequence (0.9 us per 32 channels against 0.35 us of MFMA time); two waves
+//        per SIMD overlap them: 0.070 -> 0.051 ms on layer3's 3x3, single-clip contraction time 2.76 -> 2.27 ms (the deeper ring alone:
+//        2.66; sixteen waves: 2.24).  Same K order: bit-identical to 50 / 51 (tests/test_gpu_kernels.py::test_every_x3_tile_is_bit_identical),
+//        so a clip's result does not depend on the batch it came in.
+static const int kX3DeepRingMaxWgs = 256;
 static int launch_x3(hipStream_t s, const IgemmParams& p, int groups, const McgCtx& ctx) {
   MCG_CHECK_ARG(p.Cin % 32 == 0 && (!p.x2 || p.Cin2 % 32 == 0), "igemm (f16x3): Cin=%d must be a multiple of 32", p.Cin);
   MCG_CHECK_ARG(p.Cout % 4 == 0, "igemm (f16x3): Cout=%d must be a multiple of 4", p.Cout);
@@ -170,10 +177,13 @@ static int launch_x3(hipStream_t s, const IgemmParams& p, int groups, const McgC
   }
   const long long t256 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
   int tile = p.Cout <= 64 ? 52 : (p.Cout % 256 == 0 && t256 >= 200 ? 50 : 51);
-  if (ctx.tile >= 50 && ctx.tile <= 51 && p.Cout > 64) tile = ctx.tile;
+  const long long t128 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * groups;
+  if (tile == 51 && t128 <= kX3DeepRingMaxWgs && gemm_k(p) >= 512) tile = 53;
+  if ((ctx.tile == 50 || ctx.tile == 51 || ctx.tile == 53) && p.Cout > 64) tile = ctx.tile;
   ProfRec* rec = prof_begin(ctx, s, tile, p.M, p.Cout * groups, gemm_k(p), algo_flops(p, groups), algo_bytes(p, groups, 4));
   if (tile == 50) launch_dma<float, 256, 256, 128, 4, 2, 2, 2, 1>(s, p, groups);
   else if (tile == 51) launch_dma<float, 128, 128, 128, 2, 2, 2, 2, 1>(s, p, groups);
+  else if (tile == 53) launch_dma<float, 128, 128, 128, 4, 2, 4, 1, 1>(s, p, groups);
   else launch_dma<float, 256, 64, 128, 4, 1, 2, 2, 1>(s, p, groups);
   prof_end(rec, s);
   MCG_CHECK_LAUNCH("igemm (f16x3) launch");
