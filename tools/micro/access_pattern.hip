@@ -105,7 +105,7 @@ void run(const float4* x, float4* y, int frames, int blocks, const char* name) {
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
   const double bytes = 2.0 * frames * H * W * C * 4;
-  printf("mode %d (%s), %d workgroups: %.3f ms  %.2f TB/s (read + write)\n", MODE, name, blocks, ms, bytes / ms / 1e9);
+  printf("mode %d (%s), %d workgroups: %.3f ms  %.2f TB/s (read + write) = %.1f B/clk/CU\n", MODE, name, blocks, ms, bytes / ms / 1e9, bytes / ms / 1e9 * 1e12 / (blocks < 256 ? blocks : 256) / 2.1e9);
 }
 
 int main(int argc, char** argv) {
@@ -114,6 +114,14 @@ int main(int argc, char** argv) {
   float4 *x, *y;
   hipMalloc(&x, n); hipMalloc(&y, n);
   hipMemset(x, 1, n); hipMemset(y, 0, n);
+  // fewer workgroups than CUs: what ONE CU can move with a pattern when HBM is not the limit (B/clk/CU at 2.1 GHz in the last column)
+  for (int blocks : {16, 64}) {
+    run<0>(x, y, frames / 8, blocks, "coalesced copy");
+    run<1>(x, y, frames / 8, blocks, "bneck epilogue pattern, 64-channel chunks");
+    run<5>(x, y, frames / 8, blocks, "scattered loads, 4-pixel stores");
+    run<6>(x, y, frames / 8, blocks, "4-pixel loads, scattered stores");
+    run<8>(x, y, frames / 8, blocks, "scattered loads, stores 64 B per 4 lanes");
+  }
   for (int blocks : {256}) {
     run<0>(x, y, frames, blocks, "coalesced copy");
     run<1>(x, y, frames, blocks, "bneck epilogue pattern, 64-channel chunks");
