@@ -18,7 +18,7 @@
 //     and only the order of the 16 terms inside one MFMA differs from the layer-granular kernel (parity: tests/test_gpu_kernels.py);
 //   * weights travel as 16 KiB SLABS (2 channel tiles x 4 K-steps x {high, low} x 64 lanes x 16 B, MFMA-fragment-major) in the order
 //     the tile consumes them: 9 taps of W2, then per 64-channel chunk of y the W3 slab(s) and the W1n slab(s).  ONE loader wave
-//     streams them HBM/L2 -> LDS (`buffer_load ... lds`) through a ring of five slots, four slabs ahead; the seven compute waves meet
+//     streams them HBM/L2 -> LDS (`buffer_load ... lds`) through a ring of five slots, three slabs ahead; the seven compute waves meet
 //     it at one s_barrier per slab (the loader's vmcnt covers its DMA, the barrier publishes it; nothing else orders LDS-DMA);
 //   * a workgroup owns an 8 x 28 pixel tile = 7 groups of 32 pixels = 7 compute waves.  The 10 x 30 x 64 input window of conv2 sits
 //     in LDS split ONCE into fp16 high / low chunk planes (the nine taps are immediates, conv3x3_c64.hpp's layout); the next tile's
@@ -80,6 +80,22 @@ __device__ __forceinline__ void bnx_step(const char* sl, const bf16x8& xh, const
   a1 = x3_mfma(w1h, xh, a1);
 }
 
+// LDS reads in flight across a barrier.  The compiler sinks the last K-step's MFMAs of a slab below the next slab's barrier and leaves
+// their ds_reads in flight across it.  Two things are written behind a barrier, and neither may meet such a read:
+//   * a ring slot.  The first version refilled, behind barrier kt, the slot of slab kt - 1: its reads usually return long before the DMA
+//     data does (an L2 round trip later), but not always -- with a second engine busy on the device one launch in ~200 came back with a
+//     pixel group computed from a half-overwritten weight fragment (tools/bneck_contention_probe.py, profiles/r03_x_lds_war.md).
+//     Now (i) every compute-wave barrier drains the wave's LDS reads first, and (ii) the loader refills the slot of slab kt - 2: a wave
+//     that has ARRIVED at barrier kt has issued every MFMA of slab kt - 2, i.e. holds its operands.  Five slots = three slabs of
+//     prefetch + the one being read + one draining.  Either measure alone closes the race; together they cost nothing measurable
+//     (same box: 0.945 / 0.950 / 0.940 ms for the layer1 identity block without / with one / with both).
+//   * the window planes at the K-half switch of CM = 128, re-parked right behind a barrier (drained like every other; the next tile's
+//     window is parked two barriers after the last read of this tile's).
+__device__ __forceinline__ void bnx_barrier_drained() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 template <int CM, int NSRC, int CN>
 __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams p) {
   using namespace bnx;
@@ -109,7 +125,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
   if (first >= p.total_tiles) return;
 
   if (wave == NCOMP) {
-    // ------------------------------------------------------------------ loader wave: the weight stream, four slabs ahead
+    // ------------------------------------------------------------------ loader wave: the weight stream, three slabs ahead
     const u32x4 srd_w = make_srd(p.wstream);
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)s_ring;
     const uint32_t voff = (uint32_t)lane * 16u;
@@ -120,15 +136,15 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       kt_issue = kt_issue + 1 == NS ? 0 : kt_issue + 1;
       slot_issue = slot_issue + 1 == NSLOT ? 0 : slot_issue + 1;
     };
-    static_for<NSLOT - 1>([&](auto) { issue(); });
+    static_for<NSLOT - 2>([&](auto) { issue(); });
     int tr_n = 0;
     for (int tile = first; tile < p.total_tiles; tile += stride) {
 #pragma unroll 1
       for (int kt = 0; kt < NS; ++kt) {
         if (KH == 2 && kt == NS1 / 2) __builtin_amdgcn_s_barrier();                  // the compute waves' window switch (second K half)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * (NSLOT - 2)) : "memory");   // this slab's 16 pieces have landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * (NSLOT - 3)) : "memory");   // this slab's 16 pieces have landed
         if (p.trace && blockIdx.x == 0 && lane == 0 && tr_n < 2040) { p.trace[2048 + tr_n] = __builtin_amdgcn_s_memtime(); ++tr_n; }
-        __builtin_amdgcn_s_barrier();                                                // published; the previous slab's slot is free
+        __builtin_amdgcn_s_barrier();                                                // published; the slot of slab kt - 2 is free (see bnx_barrier_drained)
         if (p.trace && blockIdx.x == 0 && lane == 0 && tr_n < 2040) { p.trace[2048 + tr_n] = __builtin_amdgcn_s_memtime(); ++tr_n; }
         issue();   // always (past the last tile it wraps to slabs nobody reads): the outstanding-piece count stays uniform
       }
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
     static_for<KH>([&](auto khc) {
       constexpr int KHI = decltype(khc)::value;
       if constexpr (KHI == 1) {                             // every wave is done with the first half's planes: park the second half
-        __builtin_amdgcn_s_barrier();
+        bnx_barrier_drained();
 #pragma unroll
         for (int it = 0; it < WIN_ROUNDS; ++it) win_park(it, w2nd[it]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -249,7 +265,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
         constexpr int TOFF = ((TAP / 3) * WW + TAP % 3) * 16;
         static_for<CM / 64>([&](auto opc) {
           constexpr int OP = decltype(opc)::value;
-          __builtin_amdgcn_s_barrier();
+          bnx_barrier_drained();
           const char* sl = slab_ptr();
           static_for<4>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
         for (int r = 0; r < 16; ++r) acc2[c][r] = 0.f;
       static_for<PARTS>([&](auto pc) {
         constexpr int PART = decltype(pc)::value;
-        __builtin_amdgcn_s_barrier();
+        bnx_barrier_drained();
         const char* sl = slab_ptr();
         static_for<4>([&](auto sc) {
           constexpr int S = decltype(sc)::value;
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       if constexpr (CN > 0) {
         static_for<CN / 64>([&](auto prc) {
           constexpr int PR = decltype(prc)::value;
-          __builtin_amdgcn_s_barrier();
+          bnx_barrier_drained();
           const char* sl = slab_ptr();
           static_for<4>([&](auto sc) {
             constexpr int S = decltype(sc)::value;

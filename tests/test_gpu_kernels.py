@@ -316,6 +316,52 @@ def test_every_x3_tile_is_bit_identical(eng, shape):
         assert torch.equal(y.view(torch.int32), outs[50].view(torch.int32)), tile
 
 
+def test_fused_bottleneck_tail_is_deterministic_under_contention(eng):
+    """bneck_x3.hpp's ring protocol under a busy device (profiles/r03_x_lds_war.md): while a second thread runs another engine's forwards on
+    its own stream, 1500 launches of the layer1 identity-block tail must reproduce the quiet launch bit for bit.  (Before the fix --
+    LDS reads left in flight across the barrier behind which the loader refills their ring slot -- about one launch in 200 did not.)"""
+    import threading
+    from mcgaze_amd import engine as E, synth
+    from mcgaze_amd.packing import bneck_stream
+    g = torch.Generator().manual_seed(1)
+    cm, cn, N, H, W = 64, 64, 70, 56, 56
+    w2 = torch.randn(cm, 3, 3, cm, generator=g) / (9 * cm / 2) ** 0.5
+    w3 = torch.randn(4 * cm, cm, generator=g) / 8
+    w1 = torch.randn(cn, 4 * cm, generator=g) / 11
+    ws, bs = bneck_stream(w2, torch.randn(cm, generator=g) * 0.1, w3, torch.randn(4 * cm, generator=g) * 0.1, w1, torch.randn(cn, generator=g) * 0.1)
+    ws, bs = ws.cuda(), bs.cuda()
+    x = torch.randn(N, H, W, cm, generator=g).relu_().cuda()
+    res = torch.randn(N, H, W, 4 * cm, generator=g).relu_().cuda()
+    ref = [t.clone() for t in E.bottleneck_x3(x, res, ws, bs, cn, 1)]
+    torch.cuda.synchronize()
+    stop, started = [False], threading.Event()
+
+    def noise():
+        other = E.HipEngine(synth.make_state_dict(0), precision='f16x3')
+        img = torch.from_numpy(synth.make_clips(7, 10, 7)).cuda()
+        s2 = torch.cuda.Stream()
+        with torch.cuda.stream(s2):
+            while not stop[0]:
+                other.forward(img, 7)
+                s2.synchronize()
+                started.set()
+    th = threading.Thread(target=noise)
+    th.start()
+    try:
+        assert started.wait(120)
+        s = torch.cuda.Stream()
+        bad = 0
+        with torch.cuda.stream(s):
+            for _ in range(1500):
+                out = E.bottleneck_x3(x, res, ws, bs, cn, 1)
+                s.synchronize()
+                bad += int(not (torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])))
+    finally:
+        stop[0] = True
+        th.join()
+    assert bad == 0, f'{bad} of 1500 launches differ from the quiet launch'
+
+
 BNECK_TOL = 4e-6   # of the tensor's scale: three chained f16x3 contractions (X3_TOL each) -- measured <= 1.2e-6
 
 

@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r03_w_gputests.log 2>&1
+grep -E "passed|failed|error" gpurun_out/r03_w_gputests.log | tail -3
