@@ -203,6 +203,37 @@ def test_pipelined_runner_matches_serial_engine(engines):
             assert torch.equal(a[k], b[k]), (i, k)
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'bf16'])
+def test_pipelined_schedule_soak(engines, precision):
+    """The production schedule (bench.py: two trunk frame ranges on concurrent streams, the decoder of batch k beside the trunk of batch
+    k + 1) run long enough to catch a rare timing-dependent fault: 120 batches cycling over three inputs, in groups of four between
+    drains, EVERY output compared bit for bit with the serial single-stream result of its input.  (The fused tail's ring race --
+    profiles/r03_x_lds_war.md -- showed once in ~200 launches under another engine's load; this is the same kind of net under the
+    engine's own concurrency.)"""
+    from mcgaze_amd.engine import PipelinedRunner
+    T, B = 7, 16
+    e = engines[precision]
+    batches = [torch.from_numpy(synth.make_clips(300 + i, B, T)).to('cuda:0') for i in range(3)]
+    e.set_option('trunk_streams', 1)
+    serial = [{k: v.clone() for k, v in e.forward(x, T).items()} for x in batches]
+    e.set_option('trunk_streams', 2)
+    torch.cuda.synchronize()
+    runner = PipelinedRunner(e, B * T, 224, 224, T)
+    ring = [dict(gaze=torch.zeros(4, B * T, 3, device='cuda:0'), boxes=torch.zeros(B * T, 3, 4, device='cuda:0'),
+                 scores=torch.zeros(B * T, 3, device='cuda:0')) for _ in range(4)]
+    bad = []
+    for group in range(30):
+        for j in range(4):
+            runner.submit(batches[(4 * group + j) % 3], ring[j])
+        runner.flush()
+        torch.cuda.synchronize()
+        for j in range(4):
+            for k in ('gaze', 'boxes', 'scores'):
+                if not torch.equal(ring[j][k], serial[(4 * group + j) % 3][k]):
+                    bad.append((4 * group + j, k))
+    assert not bad, bad[:8]
+
+
 @pytest.mark.parametrize('B,T,H,W', [(1, 33, 64, 96), (3, 1, 96, 64), (1, 2, 448, 448), (1, 101, 64, 64)])
 def test_fp32_engine_matches_oracle_on_unusual_shapes(engines, B, T, H, W):
     """Shapes the reference supports but the goldens do not cover: long clips (33 frames; 101, the longest the demo feeds:
@@ -546,16 +577,17 @@ def test_parity_fuzz_discontinuity_rate(prec):
     assert sum(seen) <= FUZZ_MAX_CROSSINGS[prec], (prec, sum(seen), len(seen))
 
 
-def test_two_threads_two_engines_one_device():
+@pytest.mark.parametrize('precision', ['f16x3', 'bf16'])
+def test_two_threads_two_engines_one_device(precision):
     """include/mcgaze_hip.h "Threading and streams": an engine runs one forward at a time, so concurrent forwards on one device take
-    one engine per thread (here: two f16x3 engines over the SAME weights, each thread on its own stream, sharing the device's
+    one engine per thread (here: two engines of one precision over the SAME weights, each thread on its own stream, sharing the device's
     side-stream pool).  Eight forwards per thread on different inputs, submitted concurrently, must reproduce the single-threaded
     results bit for bit; so must two threads hammering ONE engine (serialised by its mutex), each with its own workspace."""
     import threading
     from mcgaze_amd.engine import HipEngine
     sd = synth.make_state_dict(0)
     T, B = 7, 10                      # 70 frames: the trunk splits into two concurrent frame ranges
-    engines = [HipEngine(sd, precision='f16x3') for _ in range(2)]
+    engines = [HipEngine(sd, precision=precision) for _ in range(2)]
     imgs = [[torch.from_numpy(synth.make_clips(500 + 10 * t + i, B, T)).to('cuda:0') for i in range(4)] for t in range(2)]
     want = [[{k: v.clone() for k, v in engines[0].forward(x, T).items()} for x in imgs[t]] for t in range(2)]
     torch.cuda.synchronize()
@@ -584,7 +616,7 @@ def test_two_threads_two_engines_one_device():
                     assert torch.equal(got[t][r][k], want[t][r % 4][k]), (t, r, k)
 
     hammer(engines)                                   # one engine per thread
-    third = HipEngine(sd, precision='f16x3')          # ONE engine, two threads: HipEngine.forward re-uses its workspace, so give the
+    third = HipEngine(sd, precision=precision)          # ONE engine, two threads: HipEngine.forward re-uses its workspace, so give the
     class _OwnWs:                                     # second thread a view of the engine with its own workspace
         def __init__(self, e):
             self.e, self.ws = e, None
