@@ -136,17 +136,40 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       kt_issue = kt_issue + 1 == NS ? 0 : kt_issue + 1;
       slot_issue = slot_issue + 1 == NSLOT ? 0 : slot_issue + 1;
     };
-    static_for<NSLOT - 2>([&](auto) { issue(); });
+    // Slabs are consumed in GROUPS (the slabs that share a B operand: conv2's output pairs of one tap, conv3's K parts, the next
+    // conv1's output pairs) with one barrier per group.  occ = slabs issued and not yet released, prev = size of the group being read.
+    int occ = 0, prev = 0;
+    long long to_issue = (long long)((p.total_tiles - first + stride - 1) / stride) * NS;
+    auto fill = [&]() {
+      while (occ < NSLOT && to_issue > 0) { issue(); ++occ; --to_issue; }
+    };
+    fill();
     int tr_n = 0;
+    auto boundary = [&](auto gc) {
+      constexpr int G = decltype(gc)::value;
+      const int beyond = occ - prev - G;             // slabs issued after this group's: their pieces may still be in flight
+      if (beyond <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (beyond == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (beyond == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+      if (p.trace && blockIdx.x == 0 && lane == 0 && tr_n < 2040) { p.trace[2048 + tr_n] = __builtin_amdgcn_s_memtime(); ++tr_n; }
+      __builtin_amdgcn_s_barrier();                  // the group is published; every compute wave has drained its reads of the previous group
+      if (p.trace && blockIdx.x == 0 && lane == 0 && tr_n < 2040) { p.trace[2048 + tr_n] = __builtin_amdgcn_s_memtime(); ++tr_n; }
+      occ -= prev;
+      prev = G;
+      fill();
+    };
     for (int tile = first; tile < p.total_tiles; tile += stride) {
 #pragma unroll 1
-      for (int kt = 0; kt < NS; ++kt) {
-        if (KH == 2 && kt == NS1 / 2) __builtin_amdgcn_s_barrier();                  // the compute waves' window switch (second K half)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * (NSLOT - 3)) : "memory");   // this slab's 16 pieces have landed
-        if (p.trace && blockIdx.x == 0 && lane == 0 && tr_n < 2040) { p.trace[2048 + tr_n] = __builtin_amdgcn_s_memtime(); ++tr_n; }
-        __builtin_amdgcn_s_barrier();                                                // published; the slot of slab kt - 2 is free (see bnx_barrier_drained)
-        if (p.trace && blockIdx.x == 0 && lane == 0 && tr_n < 2040) { p.trace[2048 + tr_n] = __builtin_amdgcn_s_memtime(); ++tr_n; }
-        issue();   // always (past the last tile it wraps to slabs nobody reads): the outstanding-piece count stays uniform
+      for (int kh = 0; kh < KH; ++kh) {
+        if (kh == 1) __builtin_amdgcn_s_barrier();   // the compute waves' window switch (second K half)
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) boundary(std::integral_constant<int, CM / 64>{});
+      }
+#pragma unroll 1
+      for (int oc = 0; oc < NCH; ++oc) {
+        boundary(std::integral_constant<int, PARTS>{});
+        if constexpr (CN > 0) boundary(std::integral_constant<int, CN / 64>{});
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -199,8 +222,8 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
 
   const uint32_t a_lane = (uint32_t)lane * 16u;
   uint32_t slot = 0;                                                          // ring slot of the next slab to consume
-  auto slab_ptr = [&]() { return s_ring + slot * SLAB + a_lane; };
-  auto slab_next = [&]() { slot = slot + 1 == NSLOT ? 0 : slot + 1; };
+  auto slab_at = [&](int i) { const uint32_t t = slot + i; return s_ring + (t >= NSLOT ? t - NSLOT : t) * SLAB + a_lane; };   // i-th slab of the group
+  auto slab_adv = [&](int n) { slot = slot + n >= NSLOT ? slot + n - NSLOT : slot + n; };
 
   int tr_c = 0;
   auto stamp = [&]() {
@@ -263,18 +286,21 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       static_for<9>([&](auto tc) {
         constexpr int TAP = decltype(tc)::value;
         constexpr int TOFF = ((TAP / 3) * WW + TAP % 3) * 16;
-        static_for<CM / 64>([&](auto opc) {
-          constexpr int OP = decltype(opc)::value;
-          bnx_barrier_drained();
-          const char* sl = slab_ptr();
-          static_for<4>([&](auto jc) {
-            constexpr int J = decltype(jc)::value;
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, *(const uint4*)(bw + (4 * J) * PLANE + TOFF));
-            const bf16x8 xl = __builtin_bit_cast(bf16x8, *(const uint4*)(bw + (4 * J + 1) * PLANE + TOFF));
-            bnx_step(sl + J * 2048, xh, xl, acc1[2 * OP], acc1[2 * OP + 1]);
+        // one group per tap: its CM / 64 output-pair slabs share the window fragments
+        bnx_barrier_drained();
+        const char* sl[CM / 64];
+#pragma unroll
+        for (int op = 0; op < CM / 64; ++op) sl[op] = slab_at(op);
+        static_for<4>([&](auto jc) {
+          constexpr int J = decltype(jc)::value;
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, *(const uint4*)(bw + (4 * J) * PLANE + TOFF));
+          const bf16x8 xl = __builtin_bit_cast(bf16x8, *(const uint4*)(bw + (4 * J + 1) * PLANE + TOFF));
+          static_for<CM / 64>([&](auto opc) {
+            constexpr int OP = decltype(opc)::value;
+            bnx_step(sl[OP] + J * 2048, xh, xl, acc1[2 * OP], acc1[2 * OP + 1]);
           });
-          slab_next();
         });
+        slab_adv(CM / 64);
       });
     });
     stamp();
@@ -318,18 +344,18 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[c][r] = 0.f;
+      bnx_barrier_drained();                               // one group: the K parts of this chunk's conv3
       static_for<PARTS>([&](auto pc) {
         constexpr int PART = decltype(pc)::value;
-        bnx_barrier_drained();
-        const char* sl = slab_ptr();
+        const char* sl = slab_at(PART);
         static_for<4>([&](auto sc) {
           constexpr int S = decltype(sc)::value;
           const bf16x8 bh = PART < CM / 64 ? tfh[(PART < CM / 64 ? PART : 0) * 4 + S] : xfh[S];
           const bf16x8 bl = PART < CM / 64 ? tfl[(PART < CM / 64 ? PART : 0) * 4 + S] : xfl[S];
           bnx_step(sl + S * 2048, bh, bl, acc2[0], acc2[1]);
         });
-        slab_next();
       });
+      slab_adv(PARTS);
       // y chunk = relu(acc2 + b3 (+ res)), finished IN PLACE in the accumulators and stored
 #pragma unroll
       for (int c = 0; c < 2; ++c)
@@ -349,20 +375,22 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       // next conv1: this chunk's 64 channels of y are four K-steps; a step's B fragment is split from the accumulators when it is
       // needed (per slab: the split is 24 VALU per step, the registers of four fragments would not fit beside 128 output channels)
       if constexpr (CN > 0) {
-        static_for<CN / 64>([&](auto prc) {
-          constexpr int PR = decltype(prc)::value;
-          bnx_barrier_drained();
-          const char* sl = slab_ptr();
-          static_for<4>([&](auto sc) {
-            constexpr int S = decltype(sc)::value;
-            constexpr int YC = S >> 1, R0 = 8 * (S & 1);
-            const float v[8] = {acc2[YC][R0], acc2[YC][R0 + 1], acc2[YC][R0 + 2], acc2[YC][R0 + 3], acc2[YC][R0 + 4], acc2[YC][R0 + 5], acc2[YC][R0 + 6], acc2[YC][R0 + 7]};
-            bf16x8 yh, yl;
-            bnx_split8(v, yh, yl);
-            bnx_step(sl + S * 2048, yh, yl, acc3[2 * PR], acc3[2 * PR + 1]);
+        bnx_barrier_drained();                             // one group: the CN / 64 output-pair slabs share the split of y
+        const char* sl[CN / 64];
+#pragma unroll
+        for (int pr = 0; pr < CN / 64; ++pr) sl[pr] = slab_at(pr);
+        static_for<4>([&](auto sc) {
+          constexpr int S = decltype(sc)::value;
+          constexpr int YC = S >> 1, R0 = 8 * (S & 1);
+          const float v[8] = {acc2[YC][R0], acc2[YC][R0 + 1], acc2[YC][R0 + 2], acc2[YC][R0 + 3], acc2[YC][R0 + 4], acc2[YC][R0 + 5], acc2[YC][R0 + 6], acc2[YC][R0 + 7]};
+          bf16x8 yh, yl;
+          bnx_split8(v, yh, yl);
+          static_for<CN / 64>([&](auto prc) {
+            constexpr int PR = decltype(prc)::value;
+            bnx_step(sl[PR] + S * 2048, yh, yl, acc3[2 * PR], acc3[2 * PR + 1]);
           });
-          slab_next();
         });
+        slab_adv(CN / 64);
       }
       if (has_next) {
 #pragma unroll
