@@ -23,6 +23,9 @@ One run reports, in ONE JSON line printed by rank 0:
     -> mean angular error (degrees), every engine against the fp32 CPU oracle's outputs taken as ground truth, and the SHIFT of
     the MAE against a synthetic ground truth placed ~10.7 degrees from the oracle (north_star: within +-0.05 degrees);
   * `latency_single_clip`: one 7-frame clip per forward (BASELINE.json configs[0], the reference harness's actual usage);
+  * `host_input`: the same 64-clip step with every batch coming from (pinned) HOST memory -- f32 NCHW as the reference's collate hands it
+    over, and uint8 frames normalised on the device -- H2D on a copy stream, double-buffered under the batch pipeline, results
+    copied back: the PCIe-inclusive rate (never `value`);
   * `cpu_baseline`: the fp32 oracle on the host cores (rank 0, N = 1 only), best thread count of a sweep, median of >= 10 forwards;
   * N > 1: `world_size` (torch.distributed's), `rccl_ranks_verified` (every rank recomputes clip 0 of its ring neighbour and compares
     it bit for bit with what the all_gather delivered) and `strong_scaling` (a FIXED 512-clip batch sharded over the ranks).
@@ -97,6 +100,7 @@ def parse():
     ap.add_argument('--decoder-priority', type=int, default=-1, help='HIP stream priority of the batch pipeline\'s decoder stream (-1 = high: the default; 0 = the trunk\'s)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the cpu_baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--latency', type=int, default=1, choices=[0, 1], help='1: report single-clip latency (rank 0, N=1 only)')
+    ap.add_argument('--host-input-steps', type=int, default=20, help='timed steps of the host_input leg (rank 0, N=1 only; 0 disables)')
     ap.add_argument('--kernel-events', default='sample', choices=['sample', 'none'],
                     help="'sample': bracket every contraction-kernel launch of one UNTIMED step with HIP events (roofline)")
     return ap.parse_args()
@@ -476,6 +480,73 @@ def mae_proxy(engines, dev, n_videos, T, frames_per_video=31, src=320, cpu_threa
     return out
 
 
+def host_input_leg(eng, dev, B, T, size, steps, warmup=4):
+    """PCIe-inclusive rate of the headline engine: every batch starts in pinned HOST memory and its results end there.
+      f32:   [B*T, 3, size, size] f32, normalised (what the reference's collate hands to the model: 4 bytes per value over PCIe)
+      uint8: [B*T, size, size, 3] uint8 BGR frames (1 byte per value) -> Normalize (to_rgb) + HWC -> CHW as elementwise device work on the
+             copy stream (the dataset path's mcg_preprocess_frames does this together with crop / resize / pad: harness.run_annotation)
+    H2D on a copy stream (results return on another) into one of two device buffers (re-filled once the trunk that read it has finished), the two-deep batch pipeline
+    (decoder of batch k beside the trunk of batch k + 1), gaze / boxes / scores copied back non-blocking; the timed region ends when the
+    last batch's results are on the host."""
+    from mcgaze_amd import synth
+    from mcgaze_amd.engine import PipelinedRunner
+    N = B * T
+    out = {}
+    for mode in ('f32', 'uint8'):
+        runner = PipelinedRunner(eng, N, size, size, T)
+        copy = torch.cuda.Stream(device=dev)      # host -> device
+        ret = torch.cuda.Stream(device=dev)       # device -> host (its own stream: it waits for a decoder, the next upload must not)
+        src = torch.from_numpy(synth.make_clips(3, B, T, size, size))
+        if mode == 'uint8':
+            host = [(src.permute(0, 2, 3, 1) * 40 + 128).clamp(0, 255).to(torch.uint8).contiguous().pin_memory() for _ in range(2)]
+            stage = [torch.empty_like(host[0], device=dev) for _ in range(2)]
+            mean = torch.tensor([123.675, 116.28, 103.53], device=dev)
+            std = torch.tensor([58.395, 57.12, 57.375], device=dev)
+        else:
+            host = [src.clone().pin_memory() for _ in range(2)]
+        devb = [torch.empty(N, 3, size, size, dtype=torch.float32, device=dev) for _ in range(2)]
+        outs = [dict(gaze=torch.empty(4, N, 3, device=dev), boxes=torch.empty(N, 3, 4, device=dev), scores=torch.empty(N, 3, device=dev)) for _ in range(2)]
+        hres = [{k: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k, v in outs[0].items()} for _ in range(2)]
+        copied = [torch.cuda.Event() for _ in range(2)]
+        back = [torch.cuda.Event() for _ in range(2)]
+
+        def step(k):
+            slot = k & 1
+            with torch.cuda.stream(copy):
+                if k >= 2:
+                    copy.wait_event(runner.trunk_done[slot])           # the trunk that read this buffer has finished
+                if mode == 'uint8':
+                    stage[slot].copy_(host[slot], non_blocking=True)
+                    # Normalize (to_rgb) + HWC -> CHW on the device: elementwise, on the copy stream, part of what is timed
+                    devb[slot].copy_(((stage[slot].flip(-1).to(torch.float32) - mean) / std).permute(0, 3, 1, 2))
+                else:
+                    devb[slot].copy_(host[slot], non_blocking=True)
+                copied[slot].record(copy)
+            with torch.cuda.stream(runner.sa):
+                runner.sa.wait_event(copied[slot])
+                if k >= 2:
+                    runner.sb.wait_event(back[slot])                   # the previous results of this slot have left for the host
+                done = runner.submit(devb[slot], outs[slot])
+            with torch.cuda.stream(ret):
+                ret.wait_event(done)
+                for kk in outs[slot]:
+                    hres[slot][kk].copy_(outs[slot][kk], non_blocking=True)
+                back[slot].record(ret)
+        for k in range(warmup):
+            step(k)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            step(k)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        out[mode] = {'value': round(B * steps / el, 2), 'unit': 'clips/s', 'steps': steps, 'ms_per_step': round(el / steps * 1e3, 3),
+                     'host_to_device_MB_per_step': round(host[0].numel() * host[0].element_size() / 1e6, 1)}
+        del runner
+    out['what'] = host_input_leg.__doc__.strip().replace('\n    ', ' ')
+    return out
+
+
 def timed_leg(leg, steps, warmup, total_per_step, flops_per_clip, world):
     el = leg.timed(steps, warmup)
     v = total_per_step * steps / el
@@ -637,6 +708,8 @@ def main():
                 engines_for_mae['fp32'] = HipEngine(synth.make_state_dict(0), precision='fp32', device=dev)
             line['mae_proxy'] = mae_proxy(engines_for_mae, dev, a.mae_videos, T)
         engines_for_mae.clear()
+        if world == 1 and a.host_input_steps > 0 and a.workload == 'full' and a.pipeline:
+            line['host_input'] = host_input_leg(leg.eng, dev, B, T, a.size, a.host_input_steps)
         if world == 1 and a.latency and a.workload == 'full':
             del leg
             line['latency_single_clip'] = single_clip_latency([p for p in dict.fromkeys([a.precision, a.second_engine]) if p != 'none'], dev, T, a.size)
