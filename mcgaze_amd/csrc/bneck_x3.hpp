@@ -18,8 +18,10 @@
 //     and only the order of the 16 terms inside one MFMA differs from the layer-granular kernel (parity: tests/test_gpu_kernels.py);
 //   * weights travel as 16 KiB SLABS (2 channel tiles x 4 K-steps x {high, low} x 64 lanes x 16 B, MFMA-fragment-major) in the order
 //     the tile consumes them: 9 taps of W2, then per 64-channel chunk of y the W3 slab(s) and the W1n slab(s).  ONE loader wave
-//     streams them HBM/L2 -> LDS (`buffer_load ... lds`) through a ring of five slots, three slabs ahead; the seven compute waves meet
-//     it at one s_barrier per slab (the loader's vmcnt covers its DMA, the barrier publishes it; nothing else orders LDS-DMA);
+//     streams them HBM/L2 -> LDS (`buffer_load ... lds`) through a ring of five slots, filling whatever is free; the slabs that share a B
+//     operand form a GROUP (conv2's output pairs of one tap, conv3's K parts, the next conv1's output pairs: 1 or 2 slabs) and the seven
+//     compute waves meet the loader at one s_barrier per group (the loader's vmcnt covers its DMA, the barrier publishes it; nothing
+//     else orders LDS-DMA -- and a compute wave drains its own LDS reads before it arrives: bnx_barrier_drained);
 //   * a workgroup owns an 8 x 28 pixel tile = 7 groups of 32 pixels = 7 compute waves.  The 10 x 30 x 64 input window of conv2 sits
 //     in LDS split ONCE into fp16 high / low chunk planes (the nine taps are immediates, conv3x3_c64.hpp's layout); the next tile's
 //     window is fetched and parked by the compute waves during the 1x1 phases, when nobody reads the window.  CM = 128: the planes hold 64
@@ -85,10 +87,9 @@ __device__ __forceinline__ void bnx_step(const char* sl, const bf16x8& xh, const
 //   * a ring slot.  The first version refilled, behind barrier kt, the slot of slab kt - 1: its reads usually return long before the DMA
 //     data does (an L2 round trip later), but not always -- with a second engine busy on the device one launch in ~200 came back with a
 //     pixel group computed from a half-overwritten weight fragment (tools/bneck_contention_probe.py, profiles/r03_x_lds_war.md).
-//     Now (i) every compute-wave barrier drains the wave's LDS reads first, and (ii) the loader refills the slot of slab kt - 2: a wave
-//     that has ARRIVED at barrier kt has issued every MFMA of slab kt - 2, i.e. holds its operands.  Five slots = three slabs of
-//     prefetch + the one being read + one draining.  Either measure alone closes the race; together they cost nothing measurable
-//     (same box: 0.945 / 0.950 / 0.940 ms for the layer1 identity block without / with one / with both).
+//     Now every compute-wave barrier drains the wave's LDS reads first, so a slot is free the moment the barrier that ends its group
+//     has been passed.  (Also tried and equally safe: refilling only the slot of the slab before the previous one, bare barriers.
+//     Same box: 0.945 / 0.950 / 0.940 ms for the layer1 identity block without a fix / slack slot / drain + slack slot.)
 //   * the window planes at the K-half switch of CM = 128, re-parked right behind a barrier (drained like every other; the next tile's
 //     window is parked two barriers after the last read of this tile's).
 __device__ __forceinline__ void bnx_barrier_drained() {
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
     };
     // Slabs are consumed in GROUPS (the slabs that share a B operand: conv2's output pairs of one tap, conv3's K parts, the next
     // conv1's output pairs) with one barrier per group.  occ = slabs issued and not yet released, prev = size of the group being read.
+    // At a group's barrier the previous group's slots are released (its readers drained their LDS reads before arriving) and refilled.
     int occ = 0, prev = 0;
     long long to_issue = (long long)((p.total_tiles - first + stride - 1) / stride) * NS;
     auto fill = [&]() {
