@@ -365,7 +365,7 @@ def test_fused_bottleneck_tail_is_deterministic_under_contention(eng):
 BNECK_TOL = 4e-6   # of the tensor's scale: three chained f16x3 contractions (X3_TOL each) -- measured <= 1.2e-6
 
 
-@pytest.mark.parametrize('cm,nsrc,cn', [(64, 1, 64), (64, 1, 128), (64, 2, 64), (64, 1, 0), (64, 2, 128), (128, 1, 128), (128, 1, 0)])
+@pytest.mark.parametrize('cm,nsrc,cn', [(64, 1, 64), (64, 1, 128), (64, 2, 64), (64, 1, 0), (64, 2, 128), (64, 2, 0), (128, 1, 128), (128, 1, 0)])
 @pytest.mark.parametrize('shape', [(3, 56, 56), (2, 28, 84), (1, 9, 5), (2, 30, 37), (5, 28, 28)])
 def test_fused_bottleneck_tail_f16x3(eng, shape, cm, nsrc, cn):
     """bneck_x3.hpp (conv2 3x3 -> conv3 1x1 (+ downsample source | + residual) -> next conv1 1x1 in one kernel, the three contractions
