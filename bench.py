@@ -540,8 +540,13 @@ def host_input_leg(eng, dev, B, T, size, steps, warmup=4):
             step(k)
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
+        # what reached the host in the last step against a plain forward of the same input (outside the timed region)
+        last = (warmup + steps - 1) & 1
+        want = eng.forward(devb[last].clone(), T)
+        torch.cuda.synchronize(dev)
+        ok = all(torch.equal(hres[last][kk], want[kk].cpu()) for kk in want)
         out[mode] = {'value': round(B * steps / el, 2), 'unit': 'clips/s', 'steps': steps, 'ms_per_step': round(el / steps * 1e3, 3),
-                     'host_to_device_MB_per_step': round(host[0].numel() * host[0].element_size() / 1e6, 1)}
+                     'host_to_device_MB_per_step': round(host[0].numel() * host[0].element_size() / 1e6, 1), 'verified': bool(ok)}
         del runner
     out['what'] = host_input_leg.__doc__.strip().replace('\n    ', ' ')
     return out

@@ -234,6 +234,15 @@ def test_pipelined_schedule_soak(engines, precision):
     assert not bad, bad[:8]
 
 
+def test_bench_host_input_leg_delivers_the_forward_results(engines):
+    """bench.py `host_input` (the PCIe-inclusive rate): batches from pinned host memory through the upload stream, the batch pipeline and
+    the return stream -- what lands in host memory must be, bit for bit, a plain forward of what was uploaded (both input formats)."""
+    import bench
+    out = bench.host_input_leg(engines['f16x3'], torch.device('cuda', 0), 6, 7, 224, steps=5, warmup=3)
+    for mode in ('f32', 'uint8'):
+        assert out[mode]['verified'] is True and out[mode]['value'] > 0, (mode, out[mode])
+
+
 @pytest.mark.parametrize('B,T,H,W', [(1, 33, 64, 96), (3, 1, 96, 64), (1, 2, 448, 448), (1, 101, 64, 64)])
 def test_fp32_engine_matches_oracle_on_unusual_shapes(engines, B, T, H, W):
     """Shapes the reference supports but the goldens do not cover: long clips (33 frames; 101, the longest the demo feeds:
