@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 10
+#define MCG_ABI_VERSION 11
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
 /* MCG_F16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
@@ -100,6 +100,20 @@ int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);
 int mcg_bottleneck_x3(mcg_stream s, const float* x, const float* src2, const void* wstream, const float* bias, float* y, float* z,
                       int frames, int H, int W, int cm, int nsrc, int cn, void* trace);
 
+/* 3x3 / stride 1 / pad 1 convolution as a ONE-DIMENSIONAL Winograd F(2,3) contraction along x (MCG_F16X3 arithmetic; wino_x3.hpp): the
+ * FPN output convs (mmdet/models/necks/fpn.py:178-180) and a bottleneck's stride-1 conv2 (mmdet/models/backbones/resnet.py:263-302,
+ * layer3 / layer4) with 6 instead of 9 matrix products per output.  x [frames][H][W][Cin] f32, y [frames][H][W][Cout] f32 = conv + bias
+ * (+ ReLU); u = the weight in the kernel's transformed, split, fragment-major layout (mcgaze_amd/packing.py::wino_pack:
+ * fp16 [Cout / 128][3 Cin / 16 K steps (16-channel slice major, y tap minor)][position 4][32-channel tile 4][high, low][lane 64][8],
+ * mcg_conv3x3_wino_x3_weight_bytes(Cin, Cout) bytes = 16 / 9 of the f32 OHWI tensor).  Needs Cin % 32 == 0, Cout % 128 == 0,
+ * 2 <= W <= 62 and a 128-pair tile's input window (its rows + halo rows, 16 channels) within 48 KiB -- every level of a 224 x 224
+ * input; MCG_ERR_UNSUPPORTED otherwise (use mcg_conv2d).  The result differs from mcg_conv2d's in rounding only (both within 1e-6 of
+ * scale of the f64 convolution); it does not depend on how the frames are batched.  tile: 0 = chosen by grid size; 1 / 2 / 3 force the
+ * 128 x 128 / 64 x 64 / 32 x 64 (pairs x channels) workgroup tile -- all three give the same bits. */
+size_t mcg_conv3x3_wino_x3_weight_bytes(int Cin, int Cout);
+int mcg_conv3x3_wino_x3(mcg_stream s, const float* x, const void* u, const float* bias, float* y, int frames, int H, int W,
+                        int Cin, int Cout, int relu, int tile);
+
 /* Stem: conv 7x7 s2 p3 (3->64) + BN + ReLU then max-pool 3x3 s2 p1 (resnet.py:636-639).
  * img is the reference's NCHW f32 frame tensor.  w_stem is the packed stem weight
  * [64][7][8][4] (kw and channel zero-padded, BN folded).  ws >= mcg_stem_workspace_bytes. */
@@ -137,9 +151,16 @@ enum {
   MCG_SW_HEAD_CLS_B, /* f32 [3]                                                  */
   MCG_SW_HEAD_REG_W, /* f32 [3 clues][4][256]   (face, eyes, head)_fc_reg.weight */
   MCG_SW_HEAD_REG_B, /* f32 [3][4]                                               */
-  /* MFMA-fragment-major copies of [32 t][256] matrices for the fused row-block chain / attention block (bf16 engine; the f32 engine ignores them
-   * and may be given the row-major pointers again): WF[t][ks][lane][e] = W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e],
-   * t < 8, ks < 16, lane < 64, e < 8 -- one wave-wide 16-byte load per (column tile, K-step) is then 1 KiB contiguous. */
+  /* MFMA-fragment-major copies of [32 t][256] matrices for the fused row-block chain / attention block.
+   *   MCG_BF16:  bf16 WF[t][ks][lane][e] = W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e], t < rows / 32, ks < 16, lane < 64, e < 8 --
+   *              one wave-wide 16-byte load per (column tile, K-step) is then 1 KiB contiguous.
+   *   MCG_F16X3: REQUIRED for OUT_PROJ / CLS_FC / REG_FC / DYN (the default stage path -- chain_x3.hpp, pw_single_x3.hpp -- reads them;
+   *              passing the row-major split-packed pointer again gives WRONG results, not an error): the SPLIT fragment-major form
+   *              fp16 WF[t][ks][hl][lane][e], hl = 0 the fp16 high parts, hl = 1 the low parts of the same elements as above
+   *              (mcgaze_amd/packing.py::frag_major_split; 4 bytes per weight).  IN_PROJ_WF is not read by this engine (any pointer).
+   *              mcg_stage_forward(flags = MCG_FLAG_NO_SPECIALISED) runs the generic launch sequence, which reads only the row-major
+   *              split-packed matrices.
+   *   MCG_F32:   ignored (may be given the row-major pointers again). */
   MCG_SW_OUT_PROJ_WF, MCG_SW_CLS_FC_WF,
   MCG_SW_REG_FC_WF,  /* [3] x fragment-major */
   MCG_SW_IN_PROJ_WF, /* in_proj_weight [768][256] fragment-major (t < 24 column tiles) for the fused attention block (attn_block.hpp) */
@@ -182,9 +203,14 @@ typedef struct {
   const void* w;      /* OHWI dtype, BN folded */
   const float* bias;  /* f32 [Cout] */
   int cin, cout, k, stride, pad;
-  const void* wf;     /* optional (MCG_BF16, 1x1 convs): MFMA-fragment-major copy of w, [cout/32][cin/16][64 lanes][8]:
-                         wf[t][ks][lane][e] = w[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e].  With it the engine runs a bottleneck's
-                         conv3 (+ residual) and the next block's conv1 as one kernel (pw_pair.hpp); NULL -> layer-granular launches */
+  const void* wf;     /* optional second copy of w for a specialised kernel; NULL -> the contraction kernel on w (always correct):
+                         MCG_BF16, 1x1 convs: MFMA-fragment-major bf16 [cout/32][cin/16][64 lanes][8],
+                           wf[t][ks][lane][e] = w[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e] (pw_pair.hpp, pw_single.hpp);
+                         MCG_F16X3, 1x1 convs 256 -> 256 / 256 -> 1024: the SPLIT fragment-major form fp16 [cout/32][cin/16][high, low][64][8]
+                           (packing.py::frag_major_split; pw_single_x3.hpp).  A row-major pointer here gives wrong results;
+                         MCG_F16X3, 3x3 / stride 1 / pad 1 convs with cin % 32 == 0, cout % 128 == 0: the Winograd F(2,3) operand of
+                           mcg_conv3x3_wino_x3 (packing.py::wino_pack; wino_x3.hpp);
+                         MCG_F32: ignored */
 } mcg_conv_weights;
 
 /* A fused bottleneck tail of the MCG_F16X3 engine (bneck_x3.hpp): conv2 (3x3) -> conv3 (1x1, + downsample as a second K source or
@@ -254,7 +280,8 @@ void mcg_engine_destroy(mcg_engine* e);
  *   pointwise_pair    0/1 conv3 (+ residual) of a block and conv1 of the next as one kernel in layer1 (bf16; default 1)
  *   pointwise_stream  0/1 HBM-bound 1x1 convs (layer2, layer3 conv3, P2 / P3 laterals) by the persistent register-resident-weight
  *                     kernel pw_single.hpp (bf16; default 1)
- *   bottleneck_fused  0/1 the fused bottleneck tails handed over in mcg_model_weights.fused (f16x3; default 1) */
+ *   bottleneck_fused  0/1 the fused bottleneck tails handed over in mcg_model_weights.fused (f16x3; default 1)
+ *   winograd          0/1 stride-1 3x3 convs that carry a Winograd copy (mcg_conv_weights.wf) by wino_x3.hpp (f16x3; default 1) */
 int mcg_engine_set_option(mcg_engine* e, const char* name, int value);
 /* chunk_frames: the trunk runs in chunks of this many frames so that layer outputs stay
  * resident in the 256 MiB Infinity Cache (0 = all frames in one pass). */

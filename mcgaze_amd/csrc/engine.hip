@@ -12,6 +12,7 @@
 #include "pw_single.hpp"
 #include "bneck_x3.hpp"
 #include "pw_single_x3.hpp"
+#include "wino_x3.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -34,6 +35,7 @@ struct mcg_engine {
   mcg_conv_weights lateral[4], fpn_out[4], c3_ds[4];
   std::vector<mcg_fused_block> fused;   // f16x3: fused bottleneck tails (bneck_x3.hpp), looked up by conv2 index
   bool bneck_fused = true;
+  bool winograd = true;        // f16x3: stride-1 3x3 convs with a Winograd-packed weight copy (mcg_conv_weights.wf) run wino_x3.hpp
   const float* init_boxes;
   const void* init_feats;
   int num_stages;
@@ -193,6 +195,7 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "pointwise_pair")) e->pw_pair = value != 0;
   else if (!strcmp(name, "pointwise_stream")) e->pw_single = value != 0;
   else if (!strcmp(name, "bottleneck_fused")) e->bneck_fused = value != 0;
+  else if (!strcmp(name, "winograd")) e->winograd = value != 0;
   else { mcg_set_error("mcg_engine_set_option: unknown option '%s'", name); return MCG_ERR_ARG; }
   return MCG_OK;
 }
@@ -324,6 +327,21 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
     const int prc = launch_pw_single_x3(s, pp, cw.cout, rm == MCG_RES_NONE ? 0 : (rm == MCG_RES_ADD ? 1 : 2));
     prof_end(rec, s);
     if (prc) { mcg_set_error("pw_single_x3 launch failed"); return MCG_ERR_HIP; }
+    return MCG_OK;
+  }
+  if (dt == MCG_F16X3 && e->winograd && e->ctx.tile < 0 && cw.wf && cw.k == 3 && cw.stride == 1 && cw.pad == 1 && rm == MCG_RES_NONE &&
+      wino_x3_applicable(n, h, w, cw.cin, cw.cout)) {
+    // f16x3: the 3x3 / stride 1 convs (FPN outputs, layer3's conv2) as a 1-D Winograd F(2,3) contraction (wino_x3.hpp); FLOPs and bytes
+    // are booked as the DIRECT convolution's: the roofline keeps counting the reference's arithmetic
+    WinoParams wp;
+    memset(&wp, 0, sizeof(wp));
+    wp.x = (const float*)x; wp.u = cw.wf; wp.bias = cw.bias; wp.y = (float*)y;
+    wp.H = h; wp.W = w; wp.frames = n; wp.Cin = cw.cin; wp.Cout = cw.cout; wp.relu = relu;
+    ProfRec* rec = prof_begin(e->ctx, s, 73, (int)M, cw.cout, 9 * cw.cin, 2.0 * M * 9.0 * cw.cin * cw.cout,
+                              4.0 * ((double)M * (cw.cin + cw.cout) + 9.0 * cw.cin * cw.cout));
+    const int wrc = launch_wino_x3(s, wp);
+    prof_end(rec, s);
+    if (wrc) { mcg_set_error("wino_x3 launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
   }
   return conv2d_ctx(s, dt, &d, e->ctx);
@@ -549,6 +567,24 @@ extern "C" int mcg_bottleneck_x3(mcg_stream s, const float* x, const float* src2
   memset(&bp, 0, sizeof(bp));
   bp.x = x; bp.res = src2; bp.wstream = (const char*)wstream; bp.bias = bias; bp.y = y; bp.z = z; bp.H = H; bp.W = W; bp.trace = (unsigned long long*)trace;
   if (launch_bneck_x3((hipStream_t)s, bp, frames, cm, nsrc, cn)) { mcg_set_error("mcg_bottleneck_x3: launch failed"); return MCG_ERR_HIP; }
+  return MCG_OK;
+}
+
+extern "C" size_t mcg_conv3x3_wino_x3_weight_bytes(int Cin, int Cout) {
+  return (Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % wnx::UNT == 0) ? wino_x3_weight_bytes(Cin, Cout) : 0;
+}
+extern "C" int mcg_conv3x3_wino_x3(mcg_stream s, const float* x, const void* u, const float* bias, float* y, int frames, int H, int W,
+                                   int Cin, int Cout, int relu, int tile) {
+  MCG_CHECK_ARG(x && u && y, "mcg_conv3x3_wino_x3: null pointer");
+  MCG_CHECK_ARG(tile >= 0 && tile <= 3, "mcg_conv3x3_wino_x3: tile must be 0 (by grid size) .. 3");
+  if (!wino_x3_applicable(frames, H, W, Cin, Cout)) {
+    mcg_set_error("mcg_conv3x3_wino_x3: unsupported shape (frames=%d %dx%d, %d -> %d channels): Cin %% 32, Cout %% 128, W <= 62, window <= 48 KiB per 16 channels", frames, H, W, Cin, Cout);
+    return MCG_ERR_UNSUPPORTED;
+  }
+  WinoParams wp;
+  memset(&wp, 0, sizeof(wp));
+  wp.x = x; wp.u = u; wp.bias = bias; wp.y = y; wp.H = H; wp.W = W; wp.frames = frames; wp.Cin = Cin; wp.Cout = Cout; wp.relu = relu;
+  if (launch_wino_x3((hipStream_t)s, wp, tile - 1)) { mcg_set_error("mcg_conv3x3_wino_x3: launch failed"); return MCG_ERR_HIP; }
   return MCG_OK;
 }
 

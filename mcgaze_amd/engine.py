@@ -88,6 +88,21 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual
     return y
 
 
+def conv3x3_wino(x, w, bias=None, relu=False, tile=0):
+    """3x3 / stride 1 / pad 1 conv by the 1-D Winograd F(2,3) kernel of the MCG_F16X3 engine (mcg_conv3x3_wino_x3, wino_x3.hpp):
+    x NHWC f32, w OHWI f32 [Cout,3,3,Cin] (packed here by packing.wino_pack), bias f32 -> NHWC f32.  tile: 0 = by grid size, 1..3 forced."""
+    _require_gpu()
+    lib = L.load()
+    from .packing import wino_pack
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    u = wino_pack(w.cpu()).to(x.device)
+    assert u.numel() * 2 == lib.mcg_conv3x3_wino_x3_weight_bytes(Cin, Cout), (u.numel(), Cin, Cout)
+    y = torch.empty(N, H, W, Cout, dtype=torch.float32, device=x.device)
+    L.check(lib.mcg_conv3x3_wino_x3(_stream(), _ptr(x.contiguous()), _ptr(u), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, int(relu), tile), 'mcg_conv3x3_wino_x3')
+    return y
+
+
 def bottleneck_x3(x, src2, wstream, bias, cn, nsrc, trace=None):
     """The fused bottleneck tail (mcg_bottleneck_x3): x [N,H,W,cm] f32 = conv2's input (cm = 64 / 128), src2 = residual [N,H,W,4 cm]
     (nsrc 1) or the downsample conv's input [N,H,W,64] (nsrc 2); wstream / bias from packing.bneck_stream.
@@ -170,7 +185,7 @@ def gaze_head(gaze_w, obj, split=False):
 class HipEngine:
     """The whole per-clip forward path behind one C call (mcg_clip_forward)."""
 
-    def __init__(self, state_dict, depth=50, num_stages=4, precision='bf16', device='cuda:0', bbox_stds=(0.5, 0.5, 1.0, 1.0), fuse_downsample=True):
+    def __init__(self, state_dict, depth=50, num_stages=4, precision='f16x3', device='cuda:0', bbox_stds=(0.5, 0.5, 1.0, 1.0), fuse_downsample=True):
         _require_gpu()
         self.lib = L.load()
         self.device = torch.device(device)
@@ -212,7 +227,7 @@ class HipEngine:
 
     def set_option(self, name, value):
         """mcg_engine_set_option: 'trunk_streams', 'max_range_frames', 'tile', 'staged_gemm', 'conv3x3_c64', 'stem_fused',
-        'decoder_chain', 'pointwise_pair', 'pointwise_stream', 'bottleneck_fused' (include/mcgaze_hip.h)."""
+        'decoder_chain', 'pointwise_pair', 'pointwise_stream', 'bottleneck_fused', 'winograd' (include/mcgaze_hip.h)."""
         L.check(self.lib.mcg_engine_set_option(self._handle, name.encode(), int(value)), f'mcg_engine_set_option({name})')
 
     def profile_start(self, capacity=4096):

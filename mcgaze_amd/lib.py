@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('MCGAZE_LIB') or os.path.join(_HERE, 'libmcgaze_hip.so
 
 MCG_OK = 0
 MCG_F32, MCG_BF16, MCG_F16X3 = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 RES_NONE, RES_ADD, RES_UPSAMPLE_ADD = 0, 1, 2
 FLAG_STAGED_GEMM, FLAG_NO_SPECIALISED = 1, 2
 
@@ -30,7 +30,8 @@ EXPORTS = ['mcg_abi_version', 'mcg_last_error', 'mcg_device_info', 'mcg_nchw_to_
            'mcg_gaze_head_workspace_bytes', 'mcg_gaze_head', 'mcg_engine_create', 'mcg_engine_destroy',
            'mcg_engine_workspace_bytes', 'mcg_trunk_workspace_bytes', 'mcg_decoder_workspace_bytes', 'mcg_backbone_fpn_forward',
            'mcg_decoder_forward', 'mcg_clip_forward', 'mcg_preprocess_frames', 'mcg_engine_set_option', 'mcg_engine_profile_start',
-           'mcg_engine_profile_stop', 'mcg_bench_backbone_forward', 'mcg_bottleneck_x3', 'mcg_bench_backbone_levels']
+           'mcg_engine_profile_stop', 'mcg_bench_backbone_forward', 'mcg_bottleneck_x3', 'mcg_bench_backbone_levels', 'mcg_conv3x3_wino_x3',
+           'mcg_conv3x3_wino_x3_weight_bytes']
 
 
 class ConvDesc(C.Structure):
@@ -115,6 +116,9 @@ def load():
     lib.mcg_bench_backbone_forward.argtypes = [vp, vp, vp, i, i, i, vp, sz]
     lib.mcg_bench_backbone_levels.argtypes = [vp, vp, i, i, i, C.POINTER(vp)]
     lib.mcg_bottleneck_x3.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
+    lib.mcg_conv3x3_wino_x3.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i]
+    lib.mcg_conv3x3_wino_x3_weight_bytes.restype = sz
+    lib.mcg_conv3x3_wino_x3_weight_bytes.argtypes = [i, i]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('mcg_abi_version',):

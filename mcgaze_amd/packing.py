@@ -89,6 +89,25 @@ def split_pack(w):
     return v.reshape(*lead, 2 * K).contiguous()
 
 
+def wino_pack(w):
+    """f32 / f64 OHWI [Cout][3][3][Cin] (BN folded) -> the weight operand of wino_x3.hpp (mcg_conv3x3_wino_x3; mcg_conv_weights.wf of
+    a 3x3 conv, MCG_F16X3): the kernel row (kx) of every y tap transformed by the F(2,3) matrix G = [[1,0,0],[1/2,1/2,1/2],[-1/2,1/2,-1/2],
+    [0,0,1]] IN FLOAT64 (row 2 carries the sign flip the kernel's input transform uses), split into fp16 high / low parts
+    (hi = f16(u), lo = f16(u - hi)), laid out fp16 [Cout / 128][K step = 3 cs + ky][nu 4][channel tile 4][high, low][lane 64][8]
+    with element (nt, 3 cs + ky, nu, ct, hl, lane, e) = part hl of U_nu[128 nt + 32 ct + (lane & 31)][ky][16 cs + 8 (lane >> 5) + e]:
+    one K step's 32 KiB are contiguous and MFMA-fragment-major."""
+    cout, kh, kw, cin = w.shape
+    assert (kh, kw) == (3, 3) and cout % 128 == 0 and cin % 32 == 0, tuple(w.shape)
+    g = w.double()
+    u = torch.stack([g[:, :, 0], (g[:, :, 0] + g[:, :, 1] + g[:, :, 2]) / 2, -(g[:, :, 0] - g[:, :, 1] + g[:, :, 2]) / 2, g[:, :, 2]])   # [nu][co][ky][ci]
+    hi = u.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (u - hi.double()).clamp(-65504.0, 65504.0).to(torch.float16)
+    v = torch.stack([hi, lo])                                                  # [hl][nu][co][ky][ci]
+    v = v.reshape(2, 4, cout // 128, 4, 32, 3, cin // 16, 2, 8)                # hl, nu, nt, ct, n, ky, cs, half, e
+    v = v.permute(2, 6, 5, 1, 3, 0, 7, 4, 8)                                   # nt, cs, ky, nu, ct, hl, half, n, e
+    return v.contiguous().reshape(-1)
+
+
 def _slab(w64, chain):
     """f32 [64 out][64 k] -> one 16 KiB weight slab of bneck_x3.hpp: fp16 [2 channel tiles][4 K-steps][high, low][64 lanes][8], lane l
     holding row 32 ct + (l & 31) and, for e < 8, column 16 s + 8 (l >> 5) + e (chain = False: the 3x3 conv, whose B operand comes
@@ -164,6 +183,9 @@ class PackedWeights:
         else:
             wf1x1 = lambda w: None
 
+        # f16x3: Winograd F(2,3) copies of the stride-1 3x3 convs whose channel counts wino_x3.hpp tiles (FPN outputs, layer3 / layer4 conv2)
+        wf3x3 = (lambda w: self._dev(wino_pack(ohwi(w)))) if split else (lambda w: None)
+        wf3x3 = (lambda f: (lambda w: f(w) if (w.shape[0] % 128 == 0 and w.shape[1] % 32 == 0 and w.shape[1] >= 256) else None))(wf3x3)
         w, b = fold_bn(sd, 'backbone.conv1.weight', 'backbone.bn1')
         stem = torch.zeros(64, 7, 8, 4)
         stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
@@ -178,7 +200,8 @@ class PackedWeights:
                 stride = 2 if (bi == 0 and li > 0) else 1
                 for conv, bn, k, s, pad in (('conv1', 'bn1', 1, 1, 0), ('conv2', 'bn2', 3, stride, 1), ('conv3', 'bn3', 1, 1, 0)):
                     w, b = fold_bn(sd, f'{p}.{conv}.weight', f'{p}.{bn}')
-                    self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=k, stride=s, pad=pad, wf=wf1x1(w) if k == 1 else None))
+                    self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=k, stride=s, pad=pad,
+                                           wf=wf1x1(w) if k == 1 else (wf3x3(w) if s == 1 else None)))
                     folded.append((w, b))
                 if f'{p}.downsample.0.weight' in sd:
                     w3, b3 = w, b  # conv3 of this block (last of the loop above)
@@ -219,7 +242,7 @@ class PackedWeights:
             w = sd[f'neck.lateral_convs.{i}.conv.weight']
             self.lateral.append(dict(w=cmat(ohwi(w)), bias=vec(sd[f'neck.lateral_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=1, stride=1, pad=0, wf=wf1x1(w)))
             w = sd[f'neck.fpn_convs.{i}.conv.weight']
-            self.fpn_out.append(dict(w=cmat(ohwi(w)), bias=vec(sd[f'neck.fpn_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=3, stride=1, pad=1))
+            self.fpn_out.append(dict(w=cmat(ohwi(w)), bias=vec(sd[f'neck.fpn_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=3, stride=1, pad=1, wf=wf3x3(w)))
         self.init_boxes = vec(sd['rpn_head.init_proposal_bboxes.weight'])
         self.init_feats = self._dev(sd['rpn_head.init_proposal_features.weight'].to(dtype))   # read by a non-GEMM kernel: storage dtype
         perm = dyn_permutation()

@@ -123,6 +123,79 @@ def test_conv2d_f16x3(eng, case):
     assert err < X3_TOL, err
 
 
+WINO_CASES = [
+    # N, H, W, Cin, Cout, relu, bias   (3x3 / stride 1 / pad 1)
+    (2, 14, 14, 256, 256, True, True),      # layer3's conv2 / FPN P4
+    (1, 7, 9, 256, 256, False, True),       # odd width: the last pair of a row has a phantom pixel
+    (3, 28, 28, 64, 128, False, True),      # two blocks per window row, one channel tile column
+    (2, 56, 56, 32, 128, True, False),      # four blocks per window row (P2's geometry), no bias
+    (5, 7, 7, 512, 512, True, True),        # layer4's conv2: a tile spans several frames (zero rows between them)
+    (3, 10, 12, 96, 384, False, True),      # ragged everything
+    (1, 4, 8, 32, 128, False, True),        # a single small frame: one partly filled tile
+    (9, 5, 12, 64, 256, True, True),        # many small frames in one tile
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv3x3_wino_x3(eng, case):
+    """wino_x3.hpp (1-D Winograd F(2,3) along x in the f16x3 arithmetic) against the f64 convolution: the same bound as the direct f16x3
+    kernel, and within a small factor of that kernel's own error on the same input ("a -m gpu test of the new kernel
+    against oracle conv on ragged shapes")."""
+    N, H, W, Cin, Cout, relu, has_b = case
+    g = torch.Generator().manual_seed(4100 + WINO_CASES.index(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) if has_b else None
+    ref = F.conv2d(x.double(), w.double(), b.double() if has_b else None, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to('cuda:0')
+    y = eng.conv3x3_wino(nhwc(x), nhwc(w), b.to('cuda:0') if has_b else None, relu=relu)
+    yd = eng.conv2d(nhwc(x), nhwc(w), b.to('cuda:0') if has_b else None, pad=1, relu=relu, split=True)
+    torch.cuda.synchronize()
+    err = scale_err(y.permute(0, 3, 1, 2), ref.float())
+    err_d = scale_err(yd.permute(0, 3, 1, 2), ref.float())
+    print(f'wino f16x3 conv {case}: {err:.2e} of scale (direct f16x3 kernel: {err_d:.2e})')
+    assert err < X3_TOL, err
+    assert err < 4 * err_d + 2e-7, (err, err_d)
+
+
+def test_conv3x3_wino_x3_is_batch_invariant(eng):
+    """A frame's result must not depend on the batch it came in (tile boundaries move with the batch): frames 0..2 of a 5-frame call equal
+    a 3-frame call bit for bit."""
+    g = torch.Generator().manual_seed(4200)
+    x = torch.randn(5, 14, 14, 256, generator=g).to('cuda:0')
+    w = (torch.randn(256, 3, 3, 256, generator=g) / 48).to('cuda:0')
+    b = torch.randn(256, generator=g).to('cuda:0')
+    y5 = eng.conv3x3_wino(x, w, b, relu=True)
+    y3 = eng.conv3x3_wino(x[:3].contiguous(), w, b, relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y5[:3], y3)
+
+
+@pytest.mark.parametrize('shape', [(7, 14, 14, 256, 256), (3, 9, 11, 64, 128), (2, 28, 28, 32, 256)])
+def test_conv3x3_wino_x3_tiles_are_bit_identical(eng, shape):
+    """The three workgroup tiles of wino_x3.hpp (128 x 128, 64 x 64, 32 x 64) walk K in the same order and apply the same output transform:
+    same bits, so the tile the launcher picks from the grid size (i.e. from the batch) never shows in a result."""
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(4300 + N)
+    x = torch.randn(N, H, W, Cin, generator=g).to('cuda:0')
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to('cuda:0')
+    b = torch.randn(Cout, generator=g).to('cuda:0')
+    ys = [eng.conv3x3_wino(x, w, b, relu=True, tile=t) for t in (1, 2, 3, 0)]
+    torch.cuda.synchronize()
+    for y in ys[1:]:
+        assert torch.equal(ys[0], y)
+
+
+def test_conv3x3_wino_x3_rejects_what_it_cannot_tile(eng):
+    from mcgaze_amd import lib as L
+    x = torch.zeros(1, 8, 112, 32, device='cuda:0')
+    w = torch.zeros(128, 3, 3, 32, device='cuda:0')
+    with pytest.raises(L.McgError, match='unsupported shape'):
+        eng.conv3x3_wino(x, w)
+
+
 @pytest.mark.parametrize('wscale', [1.0, 1e-2, 1e-3])
 def test_f16x3_small_weights(eng, wscale):
     """a weight below 0.125 has its LOW half in fp16's subnormal range (absolute error 2^-25), so the split keeps fewer than

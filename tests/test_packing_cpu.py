@@ -118,3 +118,35 @@ def test_bench_roofline_bookkeeping():
     assert abs(r['achieved'] - 2.0e11 / 0.9e-3 / 1e12) < 0.01 and r['algorithmic_bytes_per_launch'] == int(3.6e9)
     assert len(r['launches']) == 4 and r['launches'][0][:4] == [50, 1000, 256, 2304] and r['algorithmic_bytes_step'] == int(2.0e8 + 1.0e8 + 1.0e6 + 3.6e9)
     assert 'three fp16 MFMAs' in r['note']
+
+
+def test_wino_pack_layout_and_transform():
+    """packing.wino_pack against the statement of wino_x3.hpp: decode the fragment-major split layout back into U_nu[co][ky][ci] and run the
+    1-D Winograd F(2,3) recurrence in float64 -- it must reproduce the direct 3x3 convolution (so the transform matrix, the sign flip of
+    position 2, the K-step order and the lane mapping are the kernel's)."""
+    import torch.nn.functional as F
+    from mcgaze_amd.packing import wino_pack
+    g = torch.Generator().manual_seed(5)
+    cout, cin, H, W = 128, 32, 5, 6
+    w = torch.randn(cout, cin, 3, 3, generator=g).double()
+    x = torch.randn(2, cin, H, W, generator=g).double()
+    u = wino_pack(w.permute(0, 2, 3, 1).contiguous())
+    assert u.dtype == torch.float16 and u.numel() * 2 == (cout // 128) * (3 * cin // 16) * 32768
+    v = u.reshape(cout // 128, cin // 16, 3, 4, 4, 2, 2, 32, 8).double()          # nt, cs, ky, nu, ct, hl, half, n, e
+    v = v.sum(dim=5)                                                               # hi + lo
+    U = v.permute(3, 0, 4, 6, 2, 1, 5, 7).reshape(4, cout, 3, cin)                 # nu, (nt ct n), ky, (cs half e)
+    gk = w.permute(0, 2, 3, 1)                                                     # co, ky, kx, ci
+    want = torch.stack([gk[:, :, 0], (gk[:, :, 0] + gk[:, :, 1] + gk[:, :, 2]) / 2, -(gk[:, :, 0] - gk[:, :, 1] + gk[:, :, 2]) / 2, gk[:, :, 2]])
+    assert float((U - want).abs().max()) < 2e-6                                    # fp16 hi + lo: 2^-22 relative of O(1) values
+    xp = F.pad(x, (1, 2, 1, 1))                                                    # x halo (one extra column for an odd tail), y halo
+    y = torch.zeros(2, cout, H, W, dtype=torch.float64)
+    for x0 in range(0, W, 2):
+        for ky in range(3):
+            d = [xp[:, :, ky:ky + H, x0 + i] for i in range(4)]                    # [N, ci, H] each: input columns x0 - 1 .. x0 + 2
+            V = [d[0] - d[2], d[1] + d[2], d[1] - d[2], d[1] - d[3]]
+            M = [torch.einsum('nch,oc->noh', V[nu], want[nu][:, ky]) for nu in range(4)]
+            y[:, :, :, x0] += M[0] + M[1] + M[2]
+            if x0 + 1 < W:
+                y[:, :, :, x0 + 1] += M[1] - M[2] - M[3]
+    ref = F.conv2d(x, w, padding=1)
+    assert float((y - ref).abs().max()) < 1e-9
