@@ -86,6 +86,7 @@ def parse():
                     help='the HEADLINE engine; f16x3 (default) is the one inside north_star\'s 1e-3 tolerance')
     ap.add_argument('--second-engine', '--parity-engine', dest='second_engine', default='bf16', choices=['bf16', 'f16x3', 'fp32', 'none'],
                     help='second engine timed in the same run and reported as a sub-object; skipped when equal to --precision')
+    ap.add_argument('--exact-steps', type=int, default=10, help='timed steps of the exact_engine leg (fp32 engine, rank 0, N = 1 only; 0 disables)')
     ap.add_argument('--second-steps', '--parity-steps', dest='second_steps', type=int, default=0, help='timed steps of the second engine (0 = steps)')
     ap.add_argument('--backbone-clips', type=int, default=32, help='BASELINE.json configs[1]: clips of the backbone-only sub-measurement (0 disables)')
     ap.add_argument('--mae-videos', type=int, default=8, help='synthetic videos of the mae_proxy leg (rank 0, N = 1 only; 0 disables)')
@@ -102,6 +103,10 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the cpu_baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--latency', type=int, default=1, choices=[0, 1], help='1: report single-clip latency (rank 0, N=1 only)')
     ap.add_argument('--host-input-steps', type=int, default=20, help='timed steps of the host_input leg (rank 0, N=1 only; 0 disables)')
+    ap.add_argument('--fake-engine', action='store_true',
+                    help='a CPU stand-in engine + gloo instead of HipEngine + RCCL: executes THIS FILE\'s N > 1 control flow (clip sharding, '
+                         'fused exchange, ring-neighbour check, strong-scaling leg, stdout hand-over) in a container without GPUs '
+                         '(tests/test_dist_cpu.py); every number in the line is meaningless and the line says so')
     ap.add_argument('--kernel-events', default='sample', choices=['sample', 'none'],
                     help="'sample': bracket every contraction-kernel launch of one UNTIMED step with HIP events (roofline)")
     return ap.parse_args()
@@ -169,6 +174,33 @@ def cpu_baseline(seconds, clip_length, size):
             'batched8_value': round(8.0 / med8, 3), 'batched8_sample': f'{len(t8)} forwards of 8 clips, median {med8:.2f} s (first is warm-up when more than one)'}
 
 
+def _sync(dev):
+    if dev.type == 'cuda':
+        torch.cuda.synchronize(dev)
+
+
+class FakeEngine:
+    """--fake-engine: HipEngine's interface on the CPU with outputs that depend on each frame's pixels only (so a clip's result does not
+    depend on its batch or rank, like the real engine's).  NOT a fallback: bench.py without the flag needs the HIP library and a GPU."""
+    device = torch.device('cpu')
+
+    def set_option(self, name, value):
+        pass
+
+    def forward(self, x, T, img_hw=None, chunk_frames=0, out=None):
+        N = x.shape[0]
+        m = torch.stack([f.double().sum() for f in x]).float() / x[0].numel()
+        gaze = torch.stack([torch.stack([torch.sin(m + k), torch.cos(m * (k + 1)), -torch.ones_like(m)], dim=-1) for k in range(4)])
+        boxes = (m[:, None, None] * torch.arange(1, 13, dtype=torch.float32).view(1, 3, 4)).abs() + 1
+        scores = (torch.sigmoid(m)[:, None].expand(N, 3) * torch.tensor([1.0, 0.9, 0.4])).contiguous()
+        res = dict(gaze=gaze, boxes=boxes, scores=scores)
+        if out is None:
+            return res
+        for k in res:
+            out[k].copy_(res[k])
+        return out
+
+
 _COMM_STREAM = {}
 
 
@@ -184,19 +216,28 @@ class Leg:
 
     def __init__(self, a, precision, dev, world, rank, dist, img, B, T, workload=None, engine=None):
         from mcgaze_amd import synth
-        from mcgaze_amd.engine import HipEngine, PipelinedRunner
         from mcgaze_amd.dist import ResultGather
         self.a, self.dev, self.dist, self.img, self.B, self.T, self.N = a, dev, dist, img, B, T, B * T
         self.precision = precision
         self.workload = workload or a.workload
-        self.eng = engine if engine is not None else HipEngine(synth.make_state_dict(0), precision=precision, device=dev)
+        self.fake = bool(a.fake_engine)
+        if engine is not None:
+            self.eng = engine
+        elif self.fake:
+            self.eng = FakeEngine()
+        else:
+            from mcgaze_amd.engine import HipEngine
+            self.eng = HipEngine(synth.make_state_dict(0), precision=precision, device=dev)
         self.eng.set_option('trunk_streams', a.trunk_streams)
         self.gathers = [ResultGather(self.N, world, dev) for _ in range(2)]   # results double-buffered like the pipeline
         self.outs = [g.local_views() for g in self.gathers]                    # the engine writes straight into the fused exchange buffers
-        self.runner = PipelinedRunner(self.eng, self.N, a.size, a.size, T, a.chunk_frames, decoder_priority=a.decoder_priority) if a.pipeline and self.workload == 'full' else None
+        self.runner = None
+        if a.pipeline and self.workload == 'full' and not self.fake:
+            from mcgaze_amd.engine import PipelinedRunner
+            self.runner = PipelinedRunner(self.eng, self.N, a.size, a.size, T, a.chunk_frames, decoder_priority=a.decoder_priority)
         # The result exchange runs on its own stream, ordered only after the decoder that produced the slot: on the caller's stream
         # it would sit between successive submits and serialise batch k+1's trunk behind batch k's decoder (the pipeline's whole point).
-        self.comm = comm_stream(dev) if dist is not None else None
+        self.comm = comm_stream(dev) if (dist is not None and not self.fake) else None
         self.gathered = [None, None]
         self.k = 0
 
@@ -210,6 +251,11 @@ class Leg:
             return
         slot = self.k & 1
         self.k += 1
+        if self.fake:   # host engine: the same engine -> fused buffer -> all_gather sequence, without streams
+            eng.forward(self.img, self.T, chunk_frames=a.chunk_frames, out=self.outs[slot])
+            if self.dist is not None:
+                self.gathers[slot].all_gather()
+            return
         cur = torch.cuda.current_stream(self.dev)
         if self.comm is not None and self.gathered[slot] is not None:
             cur.wait_event(self.gathered[slot])   # the slot's previous exchange has read the buffer the engine is about to rewrite
@@ -232,15 +278,18 @@ class Leg:
 
     def barrier(self):
         if self.dist is not None:
-            self.dist.barrier(device_ids=[self.dev.index])
-        torch.cuda.synchronize(self.dev)
+            if self.fake:
+                self.dist.barrier()
+            else:
+                self.dist.barrier(device_ids=[self.dev.index])
+        _sync(self.dev)
 
     def serial_forward(self):
         """The strictly serial schedule: one trunk stream, no batch pipeline, the caller's stream only."""
         self.eng.set_option('trunk_streams', 1)
         try:
             out = self.eng.forward(self.img, self.T, chunk_frames=self.a.chunk_frames)
-            torch.cuda.synchronize(self.dev)
+            _sync(self.dev)
         finally:
             self.eng.set_option('trunk_streams', self.a.trunk_streams)
         return out
@@ -309,7 +358,9 @@ def roofline_of(rec, precision):
     t_ms, flops, n, abytes = by[dom]
     achieved = flops / (t_ms * 1e-3) / 1e12
     peak = PEAK_F32_TFLOPS if dom < 4 else PEAK_BF16_TFLOPS
-    traffic, step_bytes, covered = None, 0.0, 0
+    traffic, step_bytes, covered, tj = None, 0.0, 0, {}
+    from mcgaze_amd import lib as _lib
+    build_id = _lib.build_id()
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
@@ -334,6 +385,9 @@ def roofline_of(rec, precision):
          'algorithmic_bytes_step': int(algo_step),
          'sampled': 'every contraction launch of one UNTIMED step after warm-up, HIP events on the launch stream, trunk on one stream '
                     '(trunk_streams=1) so a launch\'s duration is its own; the timed steps run two frame ranges on concurrent streams',
+         # the PMC file is committed evidence, not measured in this run: say which library build it was taken on
+         'traffic_build_id': tj.get('_build_id'), 'library_build_id': build_id,
+         'traffic_build_matches': bool(tj.get('_build_id') == build_id and CFG_NAMES.get(dom, '') in tj.get('_symbols_of_this_build', [])) if traffic else None,
          'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_bench_traffic.sh; FETCH_SIZE doubled per '
                            'MI355X_MICROARCH.md); bytes per launch, averaged over the symbol\'s launches; L2-miss traffic incl. Infinity-Cache hits',
          'algorithmic_bytes': 'layer-granular: inputs and residual read once, output written once, weights once (mcg_engine_profile_stop)'}
@@ -566,11 +620,11 @@ def verify_ring_neighbour(leg, world, rank, T, size, strong_b=None):
     from mcgaze_amd import synth
     q = (rank + 1) % world
     slot = (leg.k - 1) & 1
-    torch.cuda.current_stream(leg.dev).synchronize()
+    _sync(leg.dev)
     g = leg.gathers[slot]
     theirs = g.rank_views(q) if world > 1 else g.local_views()
     one = leg.eng.forward(torch.from_numpy(synth.make_clips(3 + q, 1, T, size, size)).to(leg.dev), T)
-    torch.cuda.synchronize(leg.dev)
+    _sync(leg.dev)
     ok = (torch.equal(one['gaze'], theirs['gaze'][:, :T]) and torch.equal(one['boxes'], theirs['boxes'][:T]) and torch.equal(one['scores'], theirs['scores'][:T]))
     return int(ok)
 
@@ -581,8 +635,13 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run for N > 1'
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    if a.fake_engine:   # control-flow rehearsal on the host (tests/test_dist_cpu.py): no second engine, no GPU-only legs
+        a.second_engine, a.kernel_events, a.backbone_clips, a.mae_videos, a.host_input_steps, a.latency, a.cpu_seconds = 'none', 'none', 0, 0, 0, 0, 0.0
+        a.exact_steps = 0
+        dev = torch.device('cpu')
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     dist = None
     if world > 1 or os.environ.get('MCG_BENCH_FORCE_DIST') == '1':   # the env switch exercises the exchange path on a single GPU
         import torch.distributed as dist
@@ -591,7 +650,10 @@ def main():
         # collective kernels on the high-priority queue pool, next to the decoder and exchange streams and away from the trunk's
         # (streams that share a hardware queue execute in submission order, event waits included -- engine.hip)
         os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if a.fake_engine:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from mcgaze_amd import synth
     from mcgaze_amd.dist import shard_clips
@@ -606,7 +668,7 @@ def main():
     img_np = synth.make_clips(3 + rank, B, T, a.size, a.size)
     img = torch.from_numpy(img_np).to(dev)
     flops_per_clip = {'full': FLOPS_PER_CLIP, 'backbone_fpn': FLOPS_PER_CLIP_TRUNK, 'backbone': FLOPS_PER_CLIP_BACKBONE}[a.workload]
-    want_yp = oracle_clip0(img_np, T, a.size) if (rank == 0 and a.workload == 'full') else None
+    want_yp = oracle_clip0(img_np, T, a.size) if (rank == 0 and a.workload == 'full' and not a.fake_engine) else None
 
     def run_engine(precision, steps, warmup):
         """One engine under the product schedule: sampling step, timed region, bitwise verification, deviation from the oracle,
@@ -615,7 +677,7 @@ def main():
         for _ in range(2):
             leg.step()
         leg.drain()
-        torch.cuda.synchronize(dev)
+        _sync(dev)
         roof = roofline_of(leg.sample_kernels(), precision) if a.kernel_events == 'sample' else None
         el, res = timed_leg(leg, steps, warmup, total_per_step, flops_per_clip, world)
         res['timed_region_s'] = round(el, 3)
@@ -660,6 +722,20 @@ def main():
         del sleg.runner
         sleg.runner = None
 
+    # ------------------------------------------------------------------ the exact engine beside the headline
+    exact = None
+    if world == 1 and a.exact_steps > 0 and a.workload == 'full' and 'fp32' not in (a.precision, a.second_engine):
+        del leg.runner
+        leg.runner = None
+        xleg, exact, _ = run_engine('fp32', a.exact_steps, 2)
+        if exact.get('roofline'):
+            exact['roofline'].pop('launches', None)
+        exact = dict({'dtype': 'fp32', 'what': WHAT['fp32'] + ': the reference\'s own arithmetic (f32 fma chains), reported beside the headline because the '
+                                                             'headline arithmetic carries 22-bit operands'}, **exact)
+        engines_for_mae['fp32'] = xleg.eng
+        del xleg.runner
+        xleg.runner = None
+
     # ------------------------------------------------------------------ N > 1: the fixed-batch (strong scaling) figure in the same line
     strong = None
     if world > 1 and a.strong_clips > 0 and a.global_clips == 0 and a.workload == 'full' and a.strong_clips % world == 0:
@@ -678,7 +754,8 @@ def main():
         line = {
             'metric': 'clips/sec (7x3x224x224)', 'value': head['value'], 'unit': 'clips/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True, 'scaling': scaling,
-            'vs_baseline': None, 'dtype': a.precision, 'data': 'synthetic (seeded N(0,1) clips, random-init weights, resident in HBM)',
+            'vs_baseline': None, 'dtype': a.precision,
+            'data': 'synthetic (seeded N(0,1) clips, random-init weights, resident in HBM)' if not a.fake_engine else 'FAKE ENGINE (--fake-engine: host stand-in, gloo): a rehearsal of the multi-rank control flow, every number is meaningless',
             'config': {'workload': {'full': 'full multiclue_gaze_r50 forward (R-50 + FPN + 4 decoder stages + gaze head), ', 'backbone_fpn': 'R-50 backbone + FPN only (BASELINE.json configs[1]), ', 'backbone': 'R-50 backbone only, C2..C5 (BASELINE.json configs[1]; mcg_bench_backbone_forward), '}[a.workload] +
                                    f'{B} clips/GPU x {T} frames x 3x{a.size}x{a.size}, {total_per_step} clips/step',
                        'clips_per_gpu': B, 'clip_length': T, 'global_clips': total_per_step, 'chunk_frames': a.chunk_frames,
@@ -703,6 +780,8 @@ def main():
             line['strong_scaling'] = strong
         if second is not None:
             line['throughput_engine' if a.second_engine == 'bf16' else 'second_engine'] = second
+        if exact is not None:
+            line['exact_engine'] = exact
         if head_back is not None:
             line['backbone'] = {'what': f'BASELINE.json configs[1]: R-50 backbone only (stem + layer1..4, C2..C5; mcg_bench_backbone_forward), {a.backbone_clips} clips x {T} frames x 3x{a.size}x{a.size}, '
                                         f'{FLOPS_PER_CLIP_BACKBONE / 1e9:.2f} GFLOP per clip, two concurrent frame ranges', a.precision: head_back}
@@ -734,7 +813,10 @@ def main():
     if rank != 0:
         os.dup2(2, 1)
     if dist is not None:
-        dist.barrier(device_ids=[local])
+        if a.fake_engine:
+            dist.barrier()
+        else:
+            dist.barrier(device_ids=[local])
     if line is not None:
         print(json.dumps(line), flush=True)
     os.dup2(2, 1)

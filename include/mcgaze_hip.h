@@ -45,6 +45,9 @@ typedef enum { MCG_F32 = 0, MCG_BF16 = 1, MCG_F16X3 = 2 } mcg_dtype;
 typedef void* mcg_stream; /* hipStream_t */
 
 int mcg_abi_version(void);
+/* First 16 hex digits of the sha256 over the library's kernel sources + this header at build time (csrc/Makefile); profiles/ files carry
+ * it so that a reader can tell which build a measurement belongs to. */
+const char* mcg_build_id(void);
 const char* mcg_last_error(void);
 /* Fills CU count, HBM bytes and the gcnArchName of the current HIP device. */
 int mcg_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len);

@@ -17,6 +17,10 @@ void mcg_set_error(const char* fmt, ...) {
 }
 extern "C" const char* mcg_last_error(void) { return g_err; }
 extern "C" int mcg_abi_version(void) { return MCG_ABI_VERSION; }
+#ifndef MCG_BUILD_ID
+#define MCG_BUILD_ID "unknown"
+#endif
+extern "C" const char* mcg_build_id(void) { return MCG_BUILD_ID; }
 extern "C" int mcg_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len) {
   int dev = 0;
   hipDeviceProp_t prop;
@@ -167,7 +171,17 @@ static int launch_typed(hipStream_t s, const IgemmParams& p, int groups, const M
 //        per SIMD overlap them: 0.070 -> 0.051 ms on layer3's 3x3, single-clip contraction time 2.76 -> 2.27 ms (the deeper ring alone:
 //        2.66; sixteen waves: 2.24).  Same K order: bit-identical to 50 / 51 (tests/test_gpu_kernels.py::test_every_x3_tile_is_bit_identical),
 //        so a clip's result does not depend on the batch it came in.
-static const int kX3DeepRingMaxWgs = 256;
+// "at most one workgroup per CU": the CU count of the current device, queried once per device
+static int x3_deep_ring_max_wgs() {
+  static int cus_of[MCG_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
+  if (!cus_of[dev]) {
+    hipDeviceProp_t prop;
+    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cus_of[dev];
+}
 static int launch_x3(hipStream_t s, const IgemmParams& p, int groups, const McgCtx& ctx) {
   MCG_CHECK_ARG(p.Cin % 32 == 0 && (!p.x2 || p.Cin2 % 32 == 0), "igemm (f16x3): Cin=%d must be a multiple of 32", p.Cin);
   MCG_CHECK_ARG(p.Cout % 4 == 0, "igemm (f16x3): Cout=%d must be a multiple of 4", p.Cout);
@@ -178,7 +192,7 @@ static int launch_x3(hipStream_t s, const IgemmParams& p, int groups, const McgC
   const long long t256 = (long long)((p.M + 255) / 256) * ((p.Cout + 255) / 256);
   int tile = p.Cout <= 64 ? 52 : (p.Cout % 256 == 0 && t256 >= 200 ? 50 : 51);
   const long long t128 = (long long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) * groups;
-  if (tile == 51 && t128 <= kX3DeepRingMaxWgs && gemm_k(p) >= 512) tile = 53;
+  if (tile == 51 && t128 <= x3_deep_ring_max_wgs() && gemm_k(p) >= 512) tile = 53;
   if ((ctx.tile == 50 || ctx.tile == 51 || ctx.tile == 53) && p.Cout > 64) tile = ctx.tile;
   ProfRec* rec = prof_begin(ctx, s, tile, p.M, p.Cout * groups, gemm_k(p), algo_flops(p, groups), algo_bytes(p, groups, 4));
   if (tile == 50) launch_dma<float, 256, 256, 128, 4, 2, 2, 2, 1>(s, p, groups);

@@ -25,7 +25,7 @@ GAZE_KEYS = ['FC_W', 'LN_G', 'LN_B', 'OUT_W', 'OUT_B', 'FUSE_W', 'FUSE_B']
 SW_COUNT, GW_COUNT = len(STAGE_KEYS), len(GAZE_KEYS)
 
 # every symbol include/mcgaze_hip.h declares
-EXPORTS = ['mcg_abi_version', 'mcg_last_error', 'mcg_device_info', 'mcg_nchw_to_nhwc', 'mcg_nhwc_to_nchw', 'mcg_conv2d',
+EXPORTS = ['mcg_abi_version', 'mcg_build_id', 'mcg_last_error', 'mcg_device_info', 'mcg_nchw_to_nhwc', 'mcg_nhwc_to_nchw', 'mcg_conv2d',
            'mcg_stem_workspace_bytes', 'mcg_stem_forward', 'mcg_roi_align', 'mcg_stage_workspace_bytes', 'mcg_stage_forward',
            'mcg_gaze_head_workspace_bytes', 'mcg_gaze_head', 'mcg_engine_create', 'mcg_engine_destroy',
            'mcg_engine_workspace_bytes', 'mcg_trunk_workspace_bytes', 'mcg_decoder_workspace_bytes', 'mcg_backbone_fpn_forward',
@@ -83,6 +83,7 @@ def load():
     vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
     lib.mcg_abi_version.restype = i
     lib.mcg_last_error.restype = C.c_char_p
+    lib.mcg_build_id.restype = C.c_char_p
     lib.mcg_device_info.argtypes = [C.POINTER(i), C.POINTER(sz), C.c_char_p, i]
     lib.mcg_nchw_to_nhwc.argtypes = [vp, i, vp, vp, i, i, i, i]
     lib.mcg_nhwc_to_nchw.argtypes = [vp, i, vp, vp, i, i, i, i]
@@ -127,6 +128,23 @@ def load():
         raise McgError(f'ABI mismatch: library reports {lib.mcg_abi_version()}, binding expects {ABI_VERSION}')
     _lib = lib
     return lib
+
+
+def build_id():
+    """The build id compiled into the loaded library (csrc/Makefile: sha256 over the kernel sources + the public header, 16 hex digits)."""
+    return load().mcg_build_id().decode()
+
+
+def source_id():
+    """The same hash over the sources in THIS tree: differs from build_id() when the shared library is stale."""
+    import hashlib
+    src = os.path.join(_HERE, 'csrc')
+    names = sorted(n for n in os.listdir(src) if n.endswith('.hip') or n.endswith('.hpp'))
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(os.path.join(src, n), 'rb').read())
+    h.update(open(os.path.join(_HERE, '..', 'include', 'mcgaze_hip.h'), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def check(rc, what):

@@ -446,15 +446,16 @@ def test_fused_bottleneck_tail_f16x3(eng, shape, cm, nsrc, cn):
     tiles), ragged ones (9x5, 30x37: masked pixels, partial windows) and several frames per launch (persistent grid)."""
     from mcgaze_amd.packing import bneck_stream
     N, H, W = shape
-    g = torch.Generator().manual_seed(300 + 7 * nsrc + cn + H)
-    x = torch.randn(N, 64, H, W, generator=g).relu()                      # conv1's output is post-ReLU
-    w2 = torch.randn(64, 64, 3, 3, generator=g) / np.sqrt(576 / 2)
-    b2 = torch.randn(64, generator=g) * 0.1
-    k3 = 64 * nsrc
-    w3 = torch.randn(256, k3, generator=g) / np.sqrt(k3)
-    b3 = torch.randn(256, generator=g) * 0.1
-    src2 = torch.randn(N, 64 if nsrc == 2 else 256, H, W, generator=g).relu()
-    w1n = torch.randn(cn, 256, generator=g) / np.sqrt(128) if cn else None
+    g = torch.Generator().manual_seed(300 + 7 * nsrc + cn + H + cm)
+    c = 4 * cm                                                             # block output channels (256 / 512)
+    x = torch.randn(N, cm, H, W, generator=g).relu()                      # conv1's output is post-ReLU
+    w2 = torch.randn(cm, cm, 3, 3, generator=g) / np.sqrt(9 * cm / 2)
+    b2 = torch.randn(cm, generator=g) * 0.1
+    k3 = cm + 64 * (nsrc - 1)                                              # conv3's K: t (+ the downsample conv's 64-channel input)
+    w3 = torch.randn(c, k3, generator=g) / np.sqrt(k3)
+    b3 = torch.randn(c, generator=g) * 0.1
+    src2 = torch.randn(N, 64 if nsrc == 2 else c, H, W, generator=g).relu()
+    w1n = torch.randn(cn, c, generator=g) / np.sqrt(c / 2) if cn else None
     b1n = torch.randn(cn, generator=g) * 0.1 if cn else None
     t = F.relu(F.conv2d(x.double(), w2.double(), b2.double(), padding=1))
     a = torch.cat([t, src2.double()], dim=1) if nsrc == 2 else t
@@ -469,7 +470,8 @@ def test_fused_bottleneck_tail_f16x3(eng, shape, cm, nsrc, cn):
     torch.cuda.synchronize()
     ey = scale_err(gy.permute(0, 3, 1, 2), y.float())
     ez = scale_err(gz.permute(0, 3, 1, 2), z.float()) if cn else 0.0
-    print(f'fused bottleneck tail {shape} nsrc={nsrc} cn={cn}: y {ey:.2e}, z {ez:.2e} of scale')
+    assert gy.shape[-1] == c and x.shape[1] == cm
+    print(f'fused bottleneck tail {shape} cm={cm} nsrc={nsrc} cn={cn}: y {ey:.2e}, z {ez:.2e} of scale')
     assert ey < BNECK_TOL and ez < BNECK_TOL, (ey, ez)
 
 

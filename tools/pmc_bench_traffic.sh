@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob(f'{out}/{sub}/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
-            if any(k in row['Kernel_Name'] for k in ('igemm', 'pw_pair', 'pw_single', 'bneck_x3')):
+            if any(k in row['Kernel_Name'] for k in ('igemm', 'pw_pair', 'pw_single', 'bneck_x3', 'wino_x3')):
                 agg[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
 res = {}
 for k, d in agg.items():
@@ -26,6 +26,8 @@ for k, d in agg.items():
         name = f'igemm_dma_kernel<float,{",".join(m.groups())},x3>'
     if 'pw_single_x3' in k:
         name = 'pw_single_x3_kernel (HBM-bound 256 -> 256 / 1024 convs, register-resident split weights)'
+    if 'wino_x3' in k:
+        name = 'wino_x3_kernel (3x3 / stride 1 as 1-D Winograd F(2,3); FLOPs booked as the direct convolution)'
     if 'bneck_x3' in k:
         name = 'bneck_x3_kernel (conv2 3x3 + conv3 + next conv1, layer1 / layer2 tails)'
     if 'pw_pair' in k:
@@ -44,6 +46,10 @@ for k, e in res.items():   # several instantiations may share one reported name:
 import os
 prev = json.load(open(f'{out}/../pmc_traffic.json')) if os.path.exists(f'{out}/../pmc_traffic.json') else {}
 prev.update(res)
+sys.path.insert(0, os.getcwd())
+from mcgaze_amd import lib as L
+prev['_build_id'] = L.build_id()          # which library these counters were taken on (bench.py: roofline.traffic_build_matches)
+prev['_symbols_of_this_build'] = sorted(res)
 json.dump(prev, open(f'{out}/../pmc_traffic.json', 'w'), indent=1)
 print(json.dumps(res, indent=1))
 PY
