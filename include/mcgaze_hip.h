@@ -92,6 +92,9 @@ typedef struct {
   int Cin2, stride2, H2, W2;
   int tile;             /* 0 = heuristic; else force this tile id of the contraction kernel (igemm.hip: 9, 11, 12, 14, 15; f16x3: 50, 51, 53) */
   int flags;            /* MCG_FLAG_* */
+  float wscale;         /* MCG_F16X3 only, 0 = 1: y = wscale * (x . w) + bias ...  A power of two: the caller packs w PRE-SCALED by 1 / wscale so that
+                           max |w| sits in (2^13, 2^14] and every fp16 low half down to 2^-17 of the largest weight is a NORMAL number (22 significant
+                           bits for weights of any magnitude; unscaled, a weight of 1e-3 keeps 15).  mcgaze_amd/packing.py::split_pack(scaled=True). */
 } mcg_conv_desc;
 int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);
 
@@ -112,10 +115,11 @@ int mcg_bottleneck_x3(mcg_stream s, const float* x, const float* src2, const voi
  * 2 <= W <= 62 and a 128-pair tile's input window (its rows + halo rows, 16 channels) within 48 KiB -- every level of a 224 x 224
  * input; MCG_ERR_UNSUPPORTED otherwise (use mcg_conv2d).  The result differs from mcg_conv2d's in rounding only (both within 1e-6 of
  * scale of the f64 convolution); it does not depend on how the frames are batched.  tile: 0 = chosen by grid size; 1 / 2 / 3 force the
- * 128 x 128 / 64 x 64 / 32 x 64 (pairs x channels) workgroup tile -- all three give the same bits. */
+ * 128 x 128 / 64 x 64 / 32 x 64 (pairs x channels) workgroup tile -- all three give the same bits.  wscale: as mcg_conv_desc.wscale (u packed
+ * pre-scaled by its inverse; 0 = 1). */
 size_t mcg_conv3x3_wino_x3_weight_bytes(int Cin, int Cout);
 int mcg_conv3x3_wino_x3(mcg_stream s, const float* x, const void* u, const float* bias, float* y, int frames, int H, int W,
-                        int Cin, int Cout, int relu, int tile);
+                        int Cin, int Cout, int relu, int tile, float wscale);
 
 /* Stem: conv 7x7 s2 p3 (3->64) + BN + ReLU then max-pool 3x3 s2 p1 (resnet.py:636-639).
  * img is the reference's NCHW f32 frame tensor.  w_stem is the packed stem weight
@@ -214,13 +218,16 @@ typedef struct {
                          MCG_F16X3, 3x3 / stride 1 / pad 1 convs with cin % 32 == 0, cout % 128 == 0: the Winograd F(2,3) operand of
                            mcg_conv3x3_wino_x3 (packing.py::wino_pack; wino_x3.hpp);
                          MCG_F32: ignored */
+  float wscale;       /* MCG_F16X3: the power of two w AND wf were pre-scaled by the inverse of (mcg_conv_desc.wscale); 0 = 1 = unscaled */
 } mcg_conv_weights;
 
 /* A fused bottleneck tail of the MCG_F16X3 engine (bneck_x3.hpp): conv2 (3x3) -> conv3 (1x1, + downsample as a second K source or
  * + residual) -> the NEXT block's conv1 (1x1) in one kernel; the 64-channel intermediates never leave the CU and the block output is
  * read from HBM once less.  wstream: the three weight matrices as 16 KiB MFMA-fragment-major slabs of fp16 high / low parts in
  * the order the kernel consumes them (mcgaze_amd/packing.py::bneck_stream gives the exact layout; bytes =
- * 16384 * (9 (cm / 64)^2 + (cm / 16) (cm / 64 + nsrc - 1 + cn / 64))).  bias: f32 [cm | c | cn].  Applies when cm = 64, c = 256, cn in
+ * 16384 * (9 (cm / 64)^2 + (cm / 16) (cm / 64 + nsrc - 1 + cn / 64))).  bias: f32 [cm | c | cn | 4]: the three bias vectors, then the
+ * power-of-two descale factors of conv2's, conv3's (+ downsample) and the next conv1's matrix (each packed pre-scaled by the inverse,
+ * see mcg_conv_desc.wscale) and one pad float.  Applies when cm = 64, c = 256, cn in
  * {0, 64, 128} (layer1 of a ResNet-50) or cm = 128, c = 512, cn in {0, 128}, nsrc = 1 (layer2's identity blocks); other layers keep
  * the layer-granular launches. */
 typedef struct {

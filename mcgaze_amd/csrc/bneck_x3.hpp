@@ -50,7 +50,8 @@ struct BneckParams {
   const float* x;        // conv2 input [frames][H][W][CM] f32 (the block's conv1 output)
   const float* res;      // NSRC == 1: residual [M][C];  NSRC == 2: the downsample conv's input [M][64] (block input, stride 1)
   const char* wstream;   // weight slabs in consumption order (packing.py::bneck_stream)
-  const float* bias;     // [CM conv2 | C conv3 (+ downsample) | CN next conv1]
+  const float* bias;     // [CM conv2 | C conv3 (+ downsample) | CN next conv1 | descale of W2, W3, W1n, 0]: the three matrices are packed pre-scaled by
+                         // powers of two (fp16 low halves normal), their accumulators are multiplied back before the bias (exact)
   float* y;              // [M][C]
   float* z;              // [M][CN] (CN > 0)
   int H, W, tiles_x, tiles_per_frame, total_tiles;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
   float* const s_bias = (float*)(smem + WIN_BYTES + RING_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < CM + C + CN; i += NT) s_bias[i] = p.bias[i];
+  for (int i = tid; i < CM + C + CN + 4; i += NT) s_bias[i] = p.bias[i];
   __syncthreads();
   const int first = blockIdx.x, stride = gridDim.x;
   if (first >= p.total_tiles) return;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
   const float* const s_b2 = s_bias;
   const float* const s_b3 = s_bias + CM;
   const float* const s_b1 = s_bias + CM + C;
+  const float ws2 = s_bias[CM + C + CN], ws3 = s_bias[CM + C + CN + 1], ws1 = s_bias[CM + C + CN + 2];   // descale factors (exact powers of two)
   const int ctid = tid;                                                       // 0 .. 447 among the compute lanes
 
   auto origin = [&](int t, int& n, int& ty0, int& tx0) {
@@ -315,10 +317,10 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
         const float4 b = *(const float4*)(s_b2 + c * 32 + 8 * (q0 + qq) + 4 * half);
-        v[4 * qq] = fmaxf(acc1[c][4 * (q0 + qq)] + b.x, 0.f);
-        v[4 * qq + 1] = fmaxf(acc1[c][4 * (q0 + qq) + 1] + b.y, 0.f);
-        v[4 * qq + 2] = fmaxf(acc1[c][4 * (q0 + qq) + 2] + b.z, 0.f);
-        v[4 * qq + 3] = fmaxf(acc1[c][4 * (q0 + qq) + 3] + b.w, 0.f);
+        v[4 * qq] = fmaxf(acc1[c][4 * (q0 + qq)] * ws2 + b.x, 0.f);
+        v[4 * qq + 1] = fmaxf(acc1[c][4 * (q0 + qq) + 1] * ws2 + b.y, 0.f);
+        v[4 * qq + 2] = fmaxf(acc1[c][4 * (q0 + qq) + 2] * ws2 + b.z, 0.f);
+        v[4 * qq + 3] = fmaxf(acc1[c][4 * (q0 + qq) + 3] * ws2 + b.w, 0.f);
       }
       bnx_split8(v, tfh[s], tfl[s]);
     }
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
         for (int q = 0; q < 4; ++q) {
           const int ch = oc * 64 + c * 32 + 8 * q + 4 * half;
           const float4 b = *(const float4*)(s_b3 + ch);
-          float4 o = make_float4(acc2[c][4 * q] + b.x, acc2[c][4 * q + 1] + b.y, acc2[c][4 * q + 2] + b.z, acc2[c][4 * q + 3] + b.w);
+          float4 o = make_float4(acc2[c][4 * q] * ws3 + b.x, acc2[c][4 * q + 1] * ws3 + b.y, acc2[c][4 * q + 2] * ws3 + b.z, acc2[c][4 * q + 3] * ws3 + b.w);
           if constexpr (NSRC == 1) { const float4 r = rres[SLOT][c][q]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
           o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
           if (st_ok) *(float4*)(p.y + row * C + ch) = o;
@@ -409,8 +411,8 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
         for (int q = 0; q < 4; ++q) {
           const int ch = c * 32 + 8 * q + 4 * half;
           const float4 b = *(const float4*)(s_b1 + ch);
-          const float4 o = make_float4(fmaxf(acc3[c][4 * q] + b.x, 0.f), fmaxf(acc3[c][4 * q + 1] + b.y, 0.f), fmaxf(acc3[c][4 * q + 2] + b.z, 0.f),
-                                       fmaxf(acc3[c][4 * q + 3] + b.w, 0.f));
+          const float4 o = make_float4(fmaxf(acc3[c][4 * q] * ws1 + b.x, 0.f), fmaxf(acc3[c][4 * q + 1] * ws1 + b.y, 0.f), fmaxf(acc3[c][4 * q + 2] * ws1 + b.z, 0.f),
+                                       fmaxf(acc3[c][4 * q + 3] * ws1 + b.w, 0.f));
           if (st_ok) *(float4*)(p.z + row * CN + ch) = o;
         }
     }
@@ -429,7 +431,7 @@ static inline size_t bneck_x3_stream_bytes(int cm, int nsrc, int cn) {
 
 template <int CM, int NSRC, int CN>
 static inline int launch_bneck_x3_t(hipStream_t s, const BneckParams& p) {
-  constexpr int kLds = bnx::WIN_BYTES + bnx::RING_BYTES + (CM + 4 * CM + CN) * 4;
+  constexpr int kLds = bnx::WIN_BYTES + bnx::RING_BYTES + (CM + 4 * CM + CN + 4) * 4;
   static int cus_of[MCG_MAX_DEVICES] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;

@@ -296,6 +296,7 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
   d.x = x; d.w = cw.w; d.bias = cw.bias; d.residual = res; d.y = y;
   d.N = n; d.H = h; d.W = w; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.k; d.KW = cw.k; d.stride = cw.stride; d.pad = cw.pad;
   d.relu = relu; d.residual_mode = res_mode; d.Hr = hr; d.Wr = wr;
+  d.wscale = dt == MCG_F16X3 ? cw.wscale : 0.f;
   const long long M = (long long)n * h * w;
   const int rm = res ? res_mode : MCG_RES_NONE;
   if (dt == MCG_BF16 && e->pw_single && e->ctx.tile < 0 && !e->ctx.staged && cw.wf && cw.bias && cw.k == 1 && cw.stride == 1 && cw.pad == 0 &&
@@ -319,7 +320,7 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
     PwSingleParams pp;
     memset(&pp, 0, sizeof(pp));
     pp.a = x; pp.res = res; pp.wf = cw.wf; pp.bias = cw.bias; pp.y = y;
-    pp.M = (int)M; pp.relu = relu; pp.Ho = h; pp.Wo = w;
+    pp.M = (int)M; pp.relu = relu; pp.Ho = h; pp.Wo = w; pp.wscale = cw.wscale;
     if (rm == MCG_RES_UPSAMPLE_ADD) { pp.Hr = hr; pp.Wr = wr; pp.rscale_h = (float)hr / (float)h; pp.rscale_w = (float)wr / (float)w; }
     const double res_rows = rm == MCG_RES_NONE ? 0.0 : (rm == MCG_RES_ADD ? (double)M : (double)n * hr * wr);
     ProfRec* rec = prof_begin(e->ctx, s, 71, pp.M, cw.cout, cw.cin, 2.0 * M * cw.cin * cw.cout,
@@ -336,7 +337,7 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
     WinoParams wp;
     memset(&wp, 0, sizeof(wp));
     wp.x = (const float*)x; wp.u = cw.wf; wp.bias = cw.bias; wp.y = (float*)y;
-    wp.H = h; wp.W = w; wp.frames = n; wp.Cin = cw.cin; wp.Cout = cw.cout; wp.relu = relu;
+    wp.H = h; wp.W = w; wp.frames = n; wp.Cin = cw.cin; wp.Cout = cw.cout; wp.relu = relu; wp.wscale = cw.wscale;
     ProfRec* rec = prof_begin(e->ctx, s, 73, (int)M, cw.cout, 9 * cw.cin, 2.0 * M * 9.0 * cw.cin * cw.cout,
                               4.0 * ((double)M * (cw.cin + cw.cout) + 9.0 * cw.cin * cw.cout));
     const int wrc = launch_wino_x3(s, wp);
@@ -429,6 +430,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
         mcg_conv_desc d;
         memset(&d, 0, sizeof(d));
         d.x = o2; d.w = f.w; d.bias = f.bias; d.y = y;
+        d.wscale = dt == MCG_F16X3 ? f.wscale : 0.f;
         d.N = n; d.H = ho; d.W = wo; d.Cin = c3.cin; d.Cout = c3.cout; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0; d.relu = 1;
         d.x2 = x; d.Cin2 = e->convs[ci + 3].cin; d.stride2 = e->convs[ci + 3].stride; d.H2 = h; d.W2 = w;
         MCG_TRY(conv2d_ctx(s, dt, &d, e->ctx));
@@ -574,7 +576,7 @@ extern "C" size_t mcg_conv3x3_wino_x3_weight_bytes(int Cin, int Cout) {
   return (Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % wnx::UNT == 0) ? wino_x3_weight_bytes(Cin, Cout) : 0;
 }
 extern "C" int mcg_conv3x3_wino_x3(mcg_stream s, const float* x, const void* u, const float* bias, float* y, int frames, int H, int W,
-                                   int Cin, int Cout, int relu, int tile) {
+                                   int Cin, int Cout, int relu, int tile, float wscale) {
   MCG_CHECK_ARG(x && u && y, "mcg_conv3x3_wino_x3: null pointer");
   MCG_CHECK_ARG(tile >= 0 && tile <= 3, "mcg_conv3x3_wino_x3: tile must be 0 (by grid size) .. 3");
   if (!wino_x3_applicable(frames, H, W, Cin, Cout)) {
@@ -584,6 +586,7 @@ extern "C" int mcg_conv3x3_wino_x3(mcg_stream s, const float* x, const void* u, 
   WinoParams wp;
   memset(&wp, 0, sizeof(wp));
   wp.x = x; wp.u = u; wp.bias = bias; wp.y = y; wp.H = H; wp.W = W; wp.frames = frames; wp.Cin = Cin; wp.Cout = Cout; wp.relu = relu;
+  wp.wscale = wscale;
   if (launch_wino_x3((hipStream_t)s, wp, tile - 1)) { mcg_set_error("mcg_conv3x3_wino_x3: launch failed"); return MCG_ERR_HIP; }
   return MCG_OK;
 }

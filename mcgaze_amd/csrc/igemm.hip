@@ -204,8 +204,11 @@ static int launch_x3(hipStream_t s, const IgemmParams& p, int groups, const McgC
   return MCG_OK;
 }
 
-int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p, int groups, const McgCtx& ctx) {
+int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p_in, int groups, const McgCtx& ctx) {
+  IgemmParams p = p_in;
+  if (!(p.wscale > 0.f)) p.wscale = 1.f;
   MCG_CHECK_ARG(p.M > 0 && p.Cout > 0 && groups > 0, "igemm: empty problem (M=%d Cout=%d groups=%d)", p.M, p.Cout, groups);
+  MCG_CHECK_ARG(dt == MCG_F16X3 || p.wscale == 1.f, "igemm: wscale is an MCG_F16X3 operand (got %g)", (double)p.wscale);
   if (dt == MCG_F16X3) return launch_x3(s, p, groups, ctx);
   return dt == MCG_BF16 ? launch_typed<bf16_t>(s, p, groups, ctx) : launch_typed<float>(s, p, groups, ctx);
 }
@@ -275,6 +278,7 @@ int conv2d_ctx(hipStream_t s, mcg_dtype dt, const mcg_conv_desc* d, const McgCtx
     p.xs2_w = d->Cin2; p.xs2_h = (long long)d->W2 * d->Cin2; p.xs2_n = (long long)d->H2 * d->W2 * d->Cin2;
   }
   p.splitk = 1; p.tiles_per_slice = 1 << 30;
+  p.wscale = d->wscale;
   if (dt == MCG_BF16 && d->bias && ctx.c64 && !ctx.staged && ctx.tile < 0 &&
       conv3x3_c64_applicable(d->KH, d->KW, d->stride, d->pad, d->Cin, d->Cout, p.res_mode != MCG_RES_NONE, d->x2 != nullptr)) {
     // layer1's conv2: window staged once, nine taps by address (conv3x3_c64.hpp); bit-identical to the generic kernel

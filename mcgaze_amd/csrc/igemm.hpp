@@ -39,6 +39,8 @@ struct IgemmParams {
   long long xs2_n, xs2_h;
   int xs2_w;
   int algo_k;  // algorithmic K for FLOP accounting when the packed K carries zero padding (stem); 0 = KH*KW*Cin
+  float wscale;  // f16x3: the accumulators are multiplied by this power of two before bias / residual (the weights were packed pre-scaled by its
+                 // inverse so that their fp16 low halves are normal numbers; mcg_conv_desc.wscale).  launch_igemm turns 0 into 1.
 };
 
 template <typename T, int BM, int BN, int BKB, int WAVES_M, int WAVES_N>

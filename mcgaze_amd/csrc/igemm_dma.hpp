@@ -433,6 +433,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
   const int cth = (tid % CPRO) * EPC, rth = tid / CPRO;
   const bool col_ok = n0 + cth < p.Cout;
   T* yrow = (T*)p.y + (long long)g * p.y_g + n0 + cth + (long long)(m0 + rth) * p.y_row_stride;  // + uniform row steps per store
+  const float wsc = X3 ? p.wscale : 1.f;   // exact power of two (f16x3 pre-scaled weights); 1 elsewhere
   float bv[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) bv[e] = 0.f;
@@ -466,7 +467,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
       for (int idx = tid; idx < PASS_ROWS * CPR4; idx += NT) {
         const int r = idx / CPR4, c = (idx - r * CPR4) * 4;
         const int m = mbase + r, n = n0 + c;
-        if (m < p.M && n < p.Cout) *(float4*)(P + (long long)m * p.Cout + n) = *(const float4*)(C + r * BN + c);
+        if (m < p.M && n < p.Cout) {
+          float4 t = *(const float4*)(C + r * BN + c);
+          if (X3) { t.x *= wsc; t.y *= wsc; t.z *= wsc; t.w *= wsc; }
+          *(float4*)(P + (long long)m * p.Cout + n) = t;
+        }
       }
     } else {
 #pragma unroll
@@ -477,7 +482,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void igemm_dma_kernel
 #pragma unroll
         for (int e = 0; e < EPC; e += 4) {
           const float4 t = *(const float4*)(C + r * BN + cth + e);
-          v[e] = t.x + bv[e]; v[e + 1] = t.y + bv[e + 1]; v[e + 2] = t.z + bv[e + 2]; v[e + 3] = t.w + bv[e + 3];
+          if (X3) {   // t * 2^k is exact, so this is (acc * wscale) + bias whether or not the compiler contracts it into an fma
+            v[e] = t.x * wsc + bv[e]; v[e + 1] = t.y * wsc + bv[e + 1]; v[e + 2] = t.z * wsc + bv[e + 2]; v[e + 3] = t.w * wsc + bv[e + 3];
+          } else {
+            v[e] = t.x + bv[e]; v[e + 1] = t.y + bv[e + 1]; v[e + 2] = t.z + bv[e + 2]; v[e + 3] = t.w + bv[e + 3];
+          }
         }
         if (has_res) {
           float rv[EPC];

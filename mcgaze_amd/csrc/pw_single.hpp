@@ -23,6 +23,7 @@ struct PwSingleParams {
   int M, relu, Ho, Wo, Hr, Wr;
   float rscale_h, rscale_w;
   int many_slices;          // 1: far more channel slices than XCDs (dynamic_layer: 128): workgroup id = walker * NSPLIT + slice
+  float wscale;             // f16x3 (pw_single_x3.hpp): accumulators x this power of two before the bias (pre-scaled weights); 0 = 1
 };
 
 // K = 16 KS; a workgroup owns N = 128 TPW output channels (TPW 32-channel tiles per wave, 4 waves) of the NSPLIT * N the layer has:

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256, 2) void pw_single_x3_kernel(const PwSinglePara
   const int bid = blockIdx.x, nwalkers = gridDim.x / NSPLIT;
   // ids 8 apart sit on the same XCD; many_slices (dynamic_layer: 256 slices): workgroup id = walker * NSPLIT + slice
   const int nsp = p.many_slices ? bid % NSPLIT : (bid >> 3) % NSPLIT, walker = p.many_slices ? bid / NSPLIT : (bid / (8 * NSPLIT)) * 8 + (bid & 7);
+  const float wsc = p.wscale > 0.f ? p.wscale : 1.f;   // exact power of two: the weights were packed pre-scaled by its inverse
   float4 breg[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) breg[q] = *(const float4*)(p.bias + nsp * N + wave * 32 + 8 * q + 4 * half);
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void pw_single_x3_kernel(const PwSinglePara
     for (int q = 0; q < 4; ++q) {
       const int c0 = wave * 32 + 8 * q + 4 * half;
       char* slot = s_y + y_off(px, c0 >> 2);
-      float4 v = make_float4(acc[4 * q] + breg[q].x, acc[4 * q + 1] + breg[q].y, acc[4 * q + 2] + breg[q].z, acc[4 * q + 3] + breg[q].w);
+      float4 v = make_float4(acc[4 * q] * wsc + breg[q].x, acc[4 * q + 1] * wsc + breg[q].y, acc[4 * q + 2] * wsc + breg[q].z, acc[4 * q + 3] * wsc + breg[q].w);
       if (RES) {
         const float4 rr = *(const float4*)slot;
         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;

@@ -54,6 +54,7 @@ struct WinoParams {
   float* y;              // [frames][H][W][Cout] f32
   int H, W, PW, frames, Cin, Cout, relu;
   int total_pairs, n_tiles;
+  float wscale;          // the transformed sums are multiplied by this power of two before the bias (pre-scaled weights); 0 = 1
 };
 
 // NB: 1 KiB blocks per window row = ceil((2 PW + 2) / 16).  Tile: RH x RT row tiles of 32 pairs, CT column tiles of 32 channels; 4 RH waves.
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(256 * RH, 1) void wino_x3_kernel(const WinoParams p
   const int ch4 = (tid % CPR) * 4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias) bv = *(const float4*)(p.bias + n0 + ch4);
+  const float wsc = p.wscale > 0.f ? p.wscale : 1.f;
 #pragma unroll 1
   for (int pass = 0; pass < RH; ++pass) {
     if (rh == pass) {
@@ -264,8 +266,8 @@ __global__ __launch_bounds__(256 * RH, 1) void wino_x3_kernel(const WinoParams p
       if (q < p.total_pairs) {
         const float4 m0 = *(const float4*)(C + (0 * PP + prl) * NT + ch4), m1 = *(const float4*)(C + (1 * PP + prl) * NT + ch4);
         const float4 m2 = *(const float4*)(C + (2 * PP + prl) * NT + ch4), m3 = *(const float4*)(C + (3 * PP + prl) * NT + ch4);
-        float4 y0 = make_float4(((m0.x + m1.x) + m2.x) + bv.x, ((m0.y + m1.y) + m2.y) + bv.y, ((m0.z + m1.z) + m2.z) + bv.z, ((m0.w + m1.w) + m2.w) + bv.w);
-        float4 y1 = make_float4(((m1.x - m2.x) - m3.x) + bv.x, ((m1.y - m2.y) - m3.y) + bv.y, ((m1.z - m2.z) - m3.z) + bv.z, ((m1.w - m2.w) - m3.w) + bv.w);
+        float4 y0 = make_float4(((m0.x + m1.x) + m2.x) * wsc + bv.x, ((m0.y + m1.y) + m2.y) * wsc + bv.y, ((m0.z + m1.z) + m2.z) * wsc + bv.z, ((m0.w + m1.w) + m2.w) * wsc + bv.w);
+        float4 y1 = make_float4(((m1.x - m2.x) - m3.x) * wsc + bv.x, ((m1.y - m2.y) - m3.y) * wsc + bv.y, ((m1.z - m2.z) - m3.z) * wsc + bv.z, ((m1.w - m2.w) - m3.w) * wsc + bv.w);
         if (p.relu) {
           y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
           y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);

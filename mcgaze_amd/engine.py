@@ -63,18 +63,21 @@ def to_nchw(x_nhwc):
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual_mode=L.RES_NONE, x2=None, stride2=1, split=False,
-           tile=0, flags=0):
+           tile=0, flags=0, prescale=True):
     """x NHWC, w OHWI (same dtype), bias f32 -> NHWC.  mcg_conv2d.  With x2: w = [Cout,1,1,Cin+Cin2], x2 sampled at stride2.
-    split=True: the MCG_F16X3 contraction -- x / residual f32, w given as f32 OHWI and split-packed here (packing.split_pack).
+    split=True: the MCG_F16X3 contraction -- x / residual f32, w given as f32 OHWI and split-packed here (packing.split_pack), pre-scaled
+    by a power of two unless prescale=False (packing.pow2_prescale; mcg_conv_desc.wscale).
     tile / flags: mcg_conv_desc.tile (force a contraction tile) and MCG_FLAG_* (lib.FLAG_*)."""
     _require_gpu()
     lib = L.load()
     N, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
+    wscale = 0.0
     if split:
-        from .packing import split_pack
+        from .packing import pow2_prescale, split_pack
         assert x.dtype == torch.float32 and w.dtype == torch.float32
-        w = split_pack(w.reshape(Cout, -1))
+        ws, wscale = pow2_prescale(w.reshape(Cout, -1).cpu()) if prescale else (w.reshape(Cout, -1).cpu(), 0.0)
+        w = split_pack(ws).to(x.device)
     Cin2 = x2.shape[3] if x2 is not None else 0
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     y = torch.empty(N, Ho, Wo, Cout, dtype=x.dtype, device=x.device)
@@ -83,7 +86,7 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual
                    N, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), residual_mode if residual is not None else L.RES_NONE,
                    residual.shape[1] if residual is not None else 0, residual.shape[2] if residual is not None else 0,
                    x2.data_ptr() if x2 is not None else None, Cin2, stride2, x2.shape[1] if x2 is not None else 0,
-                   x2.shape[2] if x2 is not None else 0, tile, flags)
+                   x2.shape[2] if x2 is not None else 0, tile, flags, wscale)
     L.check(lib.mcg_conv2d(_stream(), L.MCG_F16X3 if split else _code(x.dtype), C.byref(d)), 'mcg_conv2d')
     return y
 
@@ -93,13 +96,14 @@ def conv3x3_wino(x, w, bias=None, relu=False, tile=0):
     x NHWC f32, w OHWI f32 [Cout,3,3,Cin] (packed here by packing.wino_pack), bias f32 -> NHWC f32.  tile: 0 = by grid size, 1..3 forced."""
     _require_gpu()
     lib = L.load()
-    from .packing import wino_pack
+    from .packing import pow2_prescale, wino_pack
     N, H, W, Cin = x.shape
     Cout = w.shape[0]
-    u = wino_pack(w.cpu()).to(x.device)
+    ws, wscale = pow2_prescale(w.cpu())
+    u = wino_pack(ws).to(x.device)
     assert u.numel() * 2 == lib.mcg_conv3x3_wino_x3_weight_bytes(Cin, Cout), (u.numel(), Cin, Cout)
     y = torch.empty(N, H, W, Cout, dtype=torch.float32, device=x.device)
-    L.check(lib.mcg_conv3x3_wino_x3(_stream(), _ptr(x.contiguous()), _ptr(u), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, int(relu), tile), 'mcg_conv3x3_wino_x3')
+    L.check(lib.mcg_conv3x3_wino_x3(_stream(), _ptr(x.contiguous()), _ptr(u), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, int(relu), tile, wscale), 'mcg_conv3x3_wino_x3')
     return y
 
 
@@ -196,7 +200,7 @@ class HipEngine:
                                      fuse_downsample=fuse_downsample, split=self.code == L.MCG_F16X3)
         w = self.weights
         mk = lambda c: L.ConvWeights(c['w'].data_ptr(), c['bias'].data_ptr(), c['cin'], c['cout'], c['k'], c['stride'], c['pad'],
-                                     c['wf'].data_ptr() if c.get('wf') is not None else None)
+                                     c['wf'].data_ptr() if c.get('wf') is not None else None, float(c.get('wscale', 0.0)))
         self._convs = (L.ConvWeights * len(w.convs))(*[mk(c) for c in w.convs])
         self._stage_tab = (C.c_void_p * (num_stages * L.SW_COUNT))(*[st[k].data_ptr() for st in w.stages for k in L.STAGE_KEYS])
         self._gaze_tab = _table(w.gaze, L.GAZE_KEYS)

@@ -39,12 +39,12 @@ class ConvDesc(C.Structure):
                 ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('KH', C.c_int),
                 ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('relu', C.c_int), ('residual_mode', C.c_int),
                 ('Hr', C.c_int), ('Wr', C.c_int), ('x2', C.c_void_p), ('Cin2', C.c_int), ('stride2', C.c_int), ('H2', C.c_int),
-                ('W2', C.c_int), ('tile', C.c_int), ('flags', C.c_int)]
+                ('W2', C.c_int), ('tile', C.c_int), ('flags', C.c_int), ('wscale', C.c_float)]
 
 
 class ConvWeights(C.Structure):
     _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('k', C.c_int),
-                ('stride', C.c_int), ('pad', C.c_int), ('wf', C.c_void_p)]
+                ('stride', C.c_int), ('pad', C.c_int), ('wf', C.c_void_p), ('wscale', C.c_float)]
 
 
 class FusedBlock(C.Structure):
@@ -117,7 +117,7 @@ def load():
     lib.mcg_bench_backbone_forward.argtypes = [vp, vp, vp, i, i, i, vp, sz]
     lib.mcg_bench_backbone_levels.argtypes = [vp, vp, i, i, i, C.POINTER(vp)]
     lib.mcg_bottleneck_x3.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
-    lib.mcg_conv3x3_wino_x3.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i]
+    lib.mcg_conv3x3_wino_x3.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, C.c_float]
     lib.mcg_conv3x3_wino_x3_weight_bytes.restype = sz
     lib.mcg_conv3x3_wino_x3_weight_bytes.argtypes = [i, i]
     for name in EXPORTS:

@@ -64,13 +64,26 @@ def frag_major_split(w):
     """f32 [..., 32 nt out, 16 nk in] -> the MFMA-fragment-major SPLIT copy chain_x3.hpp reads: fp16 [..., t = nt][ks = nk][high, low][lane = 64][e = 8]
     with element (t, ks, hl, lane, e) = the fp16 high (hl = 0) / low part of W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e]; 4 bytes
     per weight, one wave-wide 16-byte load per (tile, K-step, part) is 1 KiB contiguous."""
-    w = w.float()
+    w = w.double()
     hi = w.clamp(-65504.0, 65504.0).to(torch.float16)
-    lo = (w - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (w - hi.double()).clamp(-65504.0, 65504.0).to(torch.float16)
     lead = w.shape[:-2]
     rows, K = w.shape[-2:]
     fh, fl = frag_major(hi).reshape(*lead, rows // 32, K // 16, 64, 8), frag_major(lo).reshape(*lead, rows // 32, K // 16, 64, 8)
     return torch.stack([fh, fl], dim=-3).reshape(*lead, rows, 2 * K).contiguous()
+
+
+def pow2_prescale(w):
+    """(w * 2^e, 2^-e) with e chosen so that max |w| * 2^e lies in (2^13, 2^14]: the exact power-of-two pre-scale of an MCG_F16X3 weight
+    matrix (include/mcgaze_hip.h: mcg_conv_desc.wscale).  An fp16 low half is a normal number down to 2^-14, i.e. for every weight within
+    2^-17 of the largest one -- unscaled, a BN-folded weight of 1e-3 keeps 15 of its 22 bits.  The kernels multiply the f32 sums by 2^-e
+    before the bias (exact).  An all-zero matrix is left alone."""
+    w = w.double()
+    m = float(w.abs().max())
+    if not (m > 0.0) or not np.isfinite(m):
+        return w, 1.0
+    e = 14 - int(np.ceil(np.log2(m)))
+    return w * (2.0 ** e), float(2.0 ** -e)
 
 
 def split_pack(w):
@@ -79,11 +92,11 @@ def split_pack(w):
     hi + lo = w to 2^-22 relative for |w| >= 0.125; a smaller weight has its low half in fp16's subnormal range (absolute error
     2^-25: |w| = 1e-2 keeps ~18 bits, 1e-3 ~15; values beyond +-65504 saturate per half; low parts below 3e-8 vanish).  4 bytes per element,
     like the f32 matrix it replaces."""
-    w = w.float()
+    w = w.double()
     K = w.shape[-1]
     assert K % 8 == 0, f'split_pack: K={K} must be a multiple of 8'
     hi = w.clamp(-65504.0, 65504.0).to(torch.float16)
-    lo = (w - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (w - hi.double()).clamp(-65504.0, 65504.0).to(torch.float16)
     lead = w.shape[:-1]
     v = torch.stack([hi.reshape(*lead, K // 8, 8), lo.reshape(*lead, K // 8, 8)], dim=-2)   # [..., K/8, 2, 8]
     return v.reshape(*lead, 2 * K).contiguous()
@@ -114,9 +127,9 @@ def _slab(w64, chain):
     from the window planes in natural order) or 16 s + 4 (l >> 5) + (e & 3) + 8 (e >> 2) (chain = True: the B operand is the previous
     contraction's accumulator registers, which hold channels {0..3, 8..11} + 4 (l >> 5) of a K-step)."""
     assert tuple(w64.shape) == (64, 64)
-    w64 = w64.float()
+    w64 = w64.double()
     hi = w64.clamp(-65504.0, 65504.0).to(torch.float16)
-    lo = (w64 - hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (w64 - hi.double()).clamp(-65504.0, 65504.0).to(torch.float16)
     lane, e, s, ct = torch.arange(64), torch.arange(8), torch.arange(4), torch.arange(2)
     half = lane >> 5
     if chain:
@@ -134,11 +147,15 @@ def bneck_stream(w2, b2, w3, b3, w1n=None, b1n=None):
     w2 [cm][3][3][cm] OHWI (cm = 64 or 128), w3 [4 cm][cm (+ 64: the downsample conv's K-concatenated input, cm = 64 only)], w1n
     [cn][4 cm] or None -- all f32 with BN folded.  Slab order = consumption order: conv2 per 64-channel K half, per tap, per 64-row
     output pair; then per 64-channel chunk oc of y: w3[oc chunk][K part] for each K part of 64, w1n[64-row pair][oc chunk] for each
-    pair.  -> (fp16 tensor of 8192 halves per slab, f32 bias [cm | 4 cm | cn])."""
+    pair.  -> (fp16 tensor of 8192 halves per slab, f32 bias [cm | 4 cm | cn | descale of w2, w3, w1n, 0])."""
     cm = w2.shape[0]
     assert cm in (64, 128) and tuple(w2.shape) == (cm, 3, 3, cm) and w3.shape[0] == 4 * cm and w3.shape[1] in ((64, 128) if cm == 64 else (128,))
     cn = 0 if w1n is None else w1n.shape[0]
     assert cn % 64 == 0 and cn <= 128 and (w1n is None or w1n.shape[1] == 4 * cm)
+    # each matrix pre-scaled by its own power of two (pow2_prescale); the descale factors ride behind the biases
+    w2, d2 = pow2_prescale(w2)
+    w3, d3 = pow2_prescale(w3)
+    w1n, d1 = pow2_prescale(w1n) if cn else (None, 1.0)
     slabs = [_slab(w2[op * 64:(op + 1) * 64, kh, kw, kk * 64:(kk + 1) * 64], chain=False)
              for kk in range(cm // 64) for kh in range(3) for kw in range(3) for op in range(cm // 64)]
     for oc in range(4 * cm // 64):
@@ -146,7 +163,7 @@ def bneck_stream(w2, b2, w3, b3, w1n=None, b1n=None):
             slabs.append(_slab(w3[oc * 64:(oc + 1) * 64, part * 64:(part + 1) * 64], chain=True))
         for pair in range(cn // 64):
             slabs.append(_slab(w1n[pair * 64:(pair + 1) * 64, oc * 64:(oc + 1) * 64], chain=True))
-    bias = torch.cat([b2.float(), b3.float()] + ([b1n.float()] if cn else []))
+    bias = torch.cat([b2.float(), b3.float()] + ([b1n.float()] if cn else []) + [torch.tensor([d2, d3, d1, 0.0], dtype=torch.float32, device=b2.device)])
     return torch.stack(slabs).reshape(-1).contiguous(), bias.contiguous()
 
 
@@ -174,6 +191,16 @@ class PackedWeights:
         # matrices: K is the trailing axis after flattening (kh, kw, cin) -- conv weights arrive here as OHWI
         mat = (lambda t: self._dev(split_pack(t))) if split else (lambda t: self._dev(t.to(dtype)))               # [..., out, in]
         cmat = (lambda t: self._dev(split_pack(t.reshape(t.shape[0], -1)))) if split else mat                      # OHWI conv weight
+
+        # one mcg_conv_weights entry from the folded OIHW weight (or an OHWI one): w, the optional second copy wf and, f16x3 trunk convs,
+        # the power-of-two pre-scale both copies carry (pow2_prescale) with its descale factor
+        def entry(w, b, k, stride, pad, wf=None, w_ohwi=None):
+            wo = ohwi(w) if w_ohwi is None else w_ohwi
+            ws = 0.0
+            if split:
+                wo, ws = pow2_prescale(wo)
+            return dict(w=cmat(wo), bias=vec(b), cin=wo.shape[3], cout=wo.shape[0], k=k, stride=stride, pad=pad,
+                        wf=wf(wo.permute(0, 3, 1, 2)) if wf is not None else None, wscale=ws)
         vec = lambda t: self._dev(t.float())
         # fragment-major copies of the 1x1 convs (bf16 engine): operands of the register-resident-weight kernels (pw_pair.hpp, pw_single.hpp)
         if dtype == torch.bfloat16:
@@ -189,7 +216,7 @@ class PackedWeights:
         w, b = fold_bn(sd, 'backbone.conv1.weight', 'backbone.bn1')
         stem = torch.zeros(64, 7, 8, 4)
         stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
-        self.stem = dict(w=cmat(stem), bias=vec(b), cin=32, cout=64, k=7, stride=2, pad=3)
+        self.stem = dict(w=cmat(stem), bias=vec(b), cin=32, cout=64, k=7, stride=2, pad=3, wscale=0.0)   # mcg_stem_forward takes no descale: unscaled
         self.convs = []
         self.fused = []  # f16x3: fused bottleneck tails (bneck_stream), dicts of wstream / bias / conv2_index / cm / c / cn / nsrc
         folded = []      # (w OIHW f32, b f32) of every entry of self.convs, for the fused tails
@@ -200,18 +227,16 @@ class PackedWeights:
                 stride = 2 if (bi == 0 and li > 0) else 1
                 for conv, bn, k, s, pad in (('conv1', 'bn1', 1, 1, 0), ('conv2', 'bn2', 3, stride, 1), ('conv3', 'bn3', 1, 1, 0)):
                     w, b = fold_bn(sd, f'{p}.{conv}.weight', f'{p}.{bn}')
-                    self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=k, stride=s, pad=pad,
-                                           wf=wf1x1(w) if k == 1 else (wf3x3(w) if s == 1 else None)))
+                    self.convs.append(entry(w, b, k, s, pad, wf=wf1x1 if k == 1 else (wf3x3 if s == 1 else None)))
                     folded.append((w, b))
                 if f'{p}.downsample.0.weight' in sd:
                     w3, b3 = w, b  # conv3 of this block (last of the loop above)
                     w, b = fold_bn(sd, f'{p}.downsample.0.weight', f'{p}.downsample.1')
-                    self.convs.append(dict(w=cmat(ohwi(w)), bias=vec(b), cin=w.shape[1], cout=w.shape[0], k=1, stride=stride, pad=0))
+                    self.convs.append(entry(w, b, 1, stride, 0))
                     folded.append((w, b))
                     if fuse_downsample:
                         wcat = torch.cat([ohwi(w3), ohwi(w)], dim=3)  # [Cout,1,1,planes + inplanes]
-                        self.c3_ds.append(dict(w=cmat(wcat), bias=vec(b3 + b), cin=wcat.shape[3], cout=wcat.shape[0], k=1, stride=1, pad=0,
-                                               wf=wf1x1(wcat.permute(0, 3, 1, 2))))
+                        self.c3_ds.append(entry(None, b3 + b, 1, 1, 0, wf=wf1x1, w_ohwi=wcat))
         if split and fuse_downsample and depth >= 50:
             # layer1 (64 mid channels; every block, the first with its downsample conv as a second K source) and layer2 (128; the
             # identity blocks -- the first block's conv2 has stride 2): conv2 -> conv3 (+ downsample | + residual) -> next conv1
@@ -240,9 +265,9 @@ class PackedWeights:
         self.lateral, self.fpn_out = [], []
         for i in range(4):
             w = sd[f'neck.lateral_convs.{i}.conv.weight']
-            self.lateral.append(dict(w=cmat(ohwi(w)), bias=vec(sd[f'neck.lateral_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=1, stride=1, pad=0, wf=wf1x1(w)))
+            self.lateral.append(entry(w, sd[f'neck.lateral_convs.{i}.conv.bias'], 1, 1, 0, wf=wf1x1))
             w = sd[f'neck.fpn_convs.{i}.conv.weight']
-            self.fpn_out.append(dict(w=cmat(ohwi(w)), bias=vec(sd[f'neck.fpn_convs.{i}.conv.bias']), cin=w.shape[1], cout=w.shape[0], k=3, stride=1, pad=1, wf=wf3x3(w)))
+            self.fpn_out.append(entry(w, sd[f'neck.fpn_convs.{i}.conv.bias'], 3, 1, 1, wf=wf3x3))
         self.init_boxes = vec(sd['rpn_head.init_proposal_bboxes.weight'])
         self.init_feats = self._dev(sd['rpn_head.init_proposal_features.weight'].to(dtype))   # read by a non-GEMM kernel: storage dtype
         perm = dyn_permutation()

@@ -48,7 +48,8 @@ def test_bneck_slab_layout_matches_the_kernel_formulas():
 
 def test_bneck_stream_order_and_sizes():
     """Slab order = consumption order (include/mcgaze_hip.h mcg_fused_block): conv2 per K half / tap / output pair, then per 64-channel
-    chunk of y the conv3 parts and the next conv1's pairs; 16 KiB per slab; bias [cm | 4 cm | cn]."""
+    chunk of y the conv3 parts and the next conv1's pairs; 16 KiB per slab; bias [cm | 4 cm | cn | the three descale factors, 0]: every
+    matrix is packed pre-scaled by its own power of two (packing.pow2_prescale)."""
     g = torch.Generator().manual_seed(6)
     for cm, k2, cn in ((64, 0, 64), (64, 64, 128), (64, 0, 0), (128, 0, 128), (128, 0, 0)):
         w2 = torch.randn(cm, 3, 3, cm, generator=g)
@@ -57,7 +58,11 @@ def test_bneck_stream_order_and_sizes():
         b = [torch.randn(n, generator=g) for n in (cm, 4 * cm, cn)]
         ws, bs = packing.bneck_stream(w2, b[0], w3, b[1], w1, b[2] if cn else None)
         nslab = 9 * (cm // 64) ** 2 + (cm // 16) * ((cm + k2) // 64 + cn // 64)
-        assert ws.numel() == nslab * 8192 and ws.dtype == torch.float16 and bs.numel() == 5 * cm + cn
+        assert ws.numel() == nslab * 8192 and ws.dtype == torch.float16 and bs.numel() == 5 * cm + cn + 4
+        (w2, d2), (w3, d3) = packing.pow2_prescale(w2), packing.pow2_prescale(w3)        # what the slabs hold
+        w1, d1 = packing.pow2_prescale(w1) if cn else (None, 1.0)
+        for m, d in ((w2, d2), (w3, d3)) + (((w1, d1),) if cn else ()):
+            assert 2.0 ** 13 < float(m.abs().max()) <= 2.0 ** 14 and np.log2(d) == round(np.log2(d))
         ws = ws.reshape(nslab, 2, 4, 2, 64, 8)
         # conv2: slab index ((kk * 9 + tap) * pairs + op)
         pairs = cm // 64
@@ -73,7 +78,7 @@ def test_bneck_stream_order_and_sizes():
         if cn:
             pr = cn // 64 - 1
             assert torch.equal(ws[base + (cm + k2) // 64 + pr], packing._slab(w1[pr * 64:(pr + 1) * 64, oc * 64:(oc + 1) * 64], chain=True))
-        assert torch.equal(bs, torch.cat([b[0], b[1]] + ([b[2]] if cn else [])))
+        assert torch.equal(bs, torch.cat([b[0], b[1]] + ([b[2]] if cn else []) + [torch.tensor([d2, d3, d1, 0.0])]))
 
 
 def test_frag_major_split_layout():
@@ -98,7 +103,7 @@ def test_packed_weights_fused_tail_table():
     assert got == [(1, 64, 256, 64, 2), (5, 64, 256, 64, 1), (8, 64, 256, 128, 1), (15, 128, 512, 128, 1), (18, 128, 512, 128, 1), (21, 128, 512, 0, 1)]
     for f in w.fused:
         nslab = 9 * (f['cm'] // 64) ** 2 + (f['cm'] // 16) * (f['cm'] // 64 + f['nsrc'] - 1 + f['cn'] // 64)
-        assert f['wstream'].numel() == nslab * 8192 and f['bias'].numel() == 5 * f['cm'] + f['cn']
+        assert f['wstream'].numel() == nslab * 8192 and f['bias'].numel() == 5 * f['cm'] + f['cn'] + 4   # + descale x 3, pad
         c2 = w.convs[f['conv2_index']]
         assert c2['k'] == 3 and c2['stride'] == 1 and c2['cin'] == f['cm']
     assert packing.PackedWeights(sd, dtype=torch.bfloat16, device='cpu').fused == []
@@ -150,3 +155,23 @@ def test_wino_pack_layout_and_transform():
                 y[:, :, :, x0 + 1] += M[1] - M[2] - M[3]
     ref = F.conv2d(x, w, padding=1)
     assert float((y - ref).abs().max()) < 1e-9
+
+
+def test_pow2_prescale_keeps_small_weights_at_22_bits():
+    """hi + lo of the PRE-SCALED matrix reproduces every weight to 2^-21 relative for weight scales 1e-4 .. 1e2 (unscaled, a
+    weight of 1e-3 keeps ~15 bits: its low half is an fp16 subnormal), the scale is an exact power of two and the descale is its inverse."""
+    g = torch.Generator().manual_seed(8)
+    for scale in (1e-4, 1e-3, 1e-2, 1.0, 1e2):
+        w = torch.randn(64, 256, generator=g).double() * scale
+        ws, d = packing.pow2_prescale(w)
+        assert np.log2(d) == round(np.log2(d)) and torch.equal(ws * d, w)
+        assert 2.0 ** 13 < float(ws.abs().max()) <= 2.0 ** 14
+        p = packing.split_pack(ws).double().reshape(64, 32, 2, 8)
+        back = (p[:, :, 0] + p[:, :, 1]).reshape(64, 256) * d
+        big = w.abs() > 2.0 ** -17 * w.abs().max()          # weights within 2^-17 of the largest keep full precision
+        rel = ((back - w).abs() / w.abs())[big]
+        assert float(rel.max()) < 2.0 ** -21, (scale, float(rel.max()))
+        raw = packing.split_pack(w).double().reshape(64, 32, 2, 8)
+        rel_raw = (((raw[:, :, 0] + raw[:, :, 1]).reshape(64, 256) - w).abs() / w.abs())[big]
+        if scale <= 1e-3:
+            assert float(rel_raw.max()) > 2.0 ** -17             # the unscaled split really is worse there
