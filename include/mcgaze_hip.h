@@ -277,8 +277,8 @@ typedef struct mcg_engine mcg_engine;
  *     one-off concurrency probe (a ~1 ms host wait on the first call that sees a new caller stream; never on the hot path
  *     afterwards).  Two engines driven concurrently on one device therefore share side streams: results are unaffected,
  *     their trunks' frame ranges may serialise against each other.
- *   - The library reads no environment variable and never synchronises the device on the hot path; mcg_engine_profile_stop
- *     and the first-call probe are the only host waits. */
+ *   - The library reads no environment variable and never synchronises the device on the hot path; mcg_engine_profile_stop,
+ *     mcg_engine_range_audit (debug) and the first-call probe are the only host waits. */
 /* The engine copies the weight TABLES (not the weights); device buffers stay caller-owned. */
 int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, mcg_dtype dt);
 void mcg_engine_destroy(mcg_engine* e);
@@ -291,8 +291,18 @@ void mcg_engine_destroy(mcg_engine* e);
  *   pointwise_stream  0/1 HBM-bound 1x1 convs (layer2, layer3 conv3, P2 / P3 laterals) by the persistent register-resident-weight
  *                     kernel pw_single.hpp (bf16; default 1)
  *   bottleneck_fused  0/1 the fused bottleneck tails handed over in mcg_model_weights.fused (f16x3; default 1)
- *   winograd          0/1 stride-1 3x3 convs that carry a Winograd copy (mcg_conv_weights.wf) by wino_x3.hpp (f16x3; default 1) */
+ *   winograd          0/1 stride-1 3x3 convs that carry a Winograd copy (mcg_conv_weights.wf) by wino_x3.hpp (f16x3; default 1)
+ *   range_audit       0/1 DEBUG (MCG_F32 / MCG_F16X3; default 0): after every activation tensor the trunk writes, a counting kernel tallies the
+ *                     values beyond the fp16 range (|x| > 65504: an f16x3 operand half would saturate there) and the non-finite ones;
+ *                     read and reset with mcg_engine_range_audit.  Turning it on allocates the counters (the library's only allocation,
+ *                     at option time); it costs a pass over every activation, so it is off in the product path. */
 int mcg_engine_set_option(mcg_engine* e, const char* name, int value);
+/* Read-out of the range_audit option: synchronises the device (a debug call), copies the counters of the first min(capacity, tensors)
+ * audited tensors to the host and resets them.  counts[2 i] = values with |x| > 65504, counts[2 i + 1] = non-finite values of tensor i,
+ * summed over every frame processed since the last read; names (optional, [capacity]) receives engine-owned tensor names ("stem",
+ * "layer3.2.conv1", "fpn.P2", ...) valid until the option changes.  A real checkpoint whose activations leave the fp16 range shows up
+ * here layer by layer instead of as a silently saturated gaze vector. */
+int mcg_engine_range_audit(mcg_engine* e, unsigned long long* counts, const char** names, int capacity, int* n_out);
 /* chunk_frames: the trunk runs in chunks of this many frames so that layer outputs stay
  * resident in the 256 MiB Infinity Cache (0 = all frames in one pass). */
 size_t mcg_engine_workspace_bytes(const mcg_engine* e, int num_frames, int H, int W, int chunk_frames);

@@ -19,6 +19,7 @@
 
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 int launch_roi_align(hipStream_t s, mcg_dtype dt, const void* const feats[4], const int feat_h[4], const int feat_w[4],
@@ -36,6 +37,11 @@ struct mcg_engine {
   std::vector<mcg_fused_block> fused;   // f16x3: fused bottleneck tails (bneck_x3.hpp), looked up by conv2 index
   bool bneck_fused = true;
   bool winograd = true;        // f16x3: stride-1 3x3 convs with a Winograd-packed weight copy (mcg_conv_weights.wf) run wino_x3.hpp
+  // range audit (debug option, f32-storage engines): per activation tensor the trunk writes, how many values lie beyond the fp16 range
+  // (|x| > 65504: an f16x3 operand half would saturate) and how many are not finite.  Counters live on the device; read by mcg_engine_range_audit.
+  static constexpr int kAuditCap = 256;
+  unsigned long long* audit_dev = nullptr;       // [kAuditCap][2]
+  std::vector<std::string> audit_names;          // filled by the first chunk that runs with the audit on
   const float* init_boxes;
   const void* init_feats;
   int num_stages;
@@ -196,6 +202,15 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "pointwise_stream")) e->pw_single = value != 0;
   else if (!strcmp(name, "bottleneck_fused")) e->bneck_fused = value != 0;
   else if (!strcmp(name, "winograd")) e->winograd = value != 0;
+  else if (!strcmp(name, "range_audit")) {
+    MCG_CHECK_ARG(e->dt != MCG_BF16 || !value, "range_audit: f32-storage engines only (MCG_F32, MCG_F16X3)");
+    if (value && !e->audit_dev) {   // set-up, not the hot path: the only allocation the library ever makes
+      if (hipMalloc((void**)&e->audit_dev, sizeof(unsigned long long) * 2 * mcg_engine::kAuditCap) != hipSuccess) { e->audit_dev = nullptr; mcg_set_error("range_audit: hipMalloc failed"); return MCG_ERR_HIP; }
+    }
+    if (value && hipMemset(e->audit_dev, 0, sizeof(unsigned long long) * 2 * mcg_engine::kAuditCap) != hipSuccess) { mcg_set_error("range_audit: hipMemset failed"); return MCG_ERR_HIP; }
+    if (!value && e->audit_dev) { (void)hipFree(e->audit_dev); e->audit_dev = nullptr; }
+    e->audit_names.clear();
+  }
   else { mcg_set_error("mcg_engine_set_option: unknown option '%s'", name); return MCG_ERR_ARG; }
   return MCG_OK;
 }
@@ -259,7 +274,36 @@ extern "C" void mcg_engine_destroy(mcg_engine* e) {
     for (int i = 0; i < e->prof.cap; ++i) { (void)hipEventDestroy(e->prof.recs[i].a); (void)hipEventDestroy(e->prof.recs[i].b); }
     delete[] e->prof.recs;
   }
+  if (e->audit_dev) (void)hipFree(e->audit_dev);
   delete e;
+}
+
+// ---------------------------------------------------------------- range audit (debug option)
+__global__ void range_audit_kernel(const float* __restrict__ x, long long n, unsigned long long* __restrict__ cnt) {
+  unsigned long long big = 0, bad = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (!(fabsf(v) <= 3.4028235e38f)) ++bad;       // inf or nan
+    else if (fabsf(v) > 65504.f) ++big;
+  }
+  big = (unsigned long long)wave_sum((float)big) ;  // counts per wave stay far below 2^24: exact in f32
+  bad = (unsigned long long)wave_sum((float)bad);
+  if ((threadIdx.x & 63) == 0) {
+    if (big) atomicAdd(cnt, big);
+    if (bad) atomicAdd(cnt + 1, bad);
+  }
+}
+// One audited tensor: slot idx of the chunk's sequence (the same for every chunk and frame range, so the counters add up over the batch)
+struct AuditCursor { mcg_engine* e; hipStream_t s; int idx; bool naming; };
+static void audit_tensor(AuditCursor& a, const char* name, const void* p, long long elements) {
+  if (!a.e->audit_dev || a.idx >= mcg_engine::kAuditCap) return;
+  if (a.naming) a.e->audit_names.push_back(name);
+  const long long per_thread = 16;
+  long long blocks = (elements + 256 * per_thread - 1) / (256 * per_thread);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(range_audit_kernel, dim3((int)blocks), dim3(256), 0, a.s, (const float*)p, elements, a.e->audit_dev + 2 * a.idx);
+  ++a.idx;
 }
 
 // ---------------------------------------------------------------- trunk workspace for one chunk of n frames
@@ -355,6 +399,9 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
   const size_t es = esize(dt);
   TrunkWs t = trunk_layout(dt, n, H, W, wsbase);
   MCG_TRY(stem_forward_ctx(s, dt, img + (size_t)f0 * 3 * H * W, e->stem.w, e->stem.bias, t.x0, n, H, W, t.stem_ws, t.stem_bytes, e->ctx));
+  AuditCursor au{e, s, 0, e->audit_dev != nullptr && e->audit_names.empty()};
+  char aname[64];
+  audit_tensor(au, "stem", t.x0, (long long)n * (H / 4) * (W / 4) * 64);
   const void* x = t.x0;
   int h = H / 4, w = W / 4, ci = 0;
   bool o1_ready = false;   // o1 already holds this block's conv1 output (written by the previous block's pointwise-pair / fused-tail kernel)
@@ -365,7 +412,11 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
       const bool has_ds = b == 0;
       const int ho = (h + 2 * c2.pad - c2.k) / c2.stride + 1, wo = (w + 2 * c2.pad - c2.k) / c2.stride + 1;
       void* y = (b == e->blocks[l] - 1) ? (void*)t.c[l] : (x == t.xa ? (void*)t.xb : (void*)t.xa);
-      if (!o1_ready) MCG_TRY(conv_call(e, s, dt, c1, x, n, h, w, o1, 1, nullptr, MCG_RES_NONE, 0, 0));
+      if (!o1_ready) {
+        MCG_TRY(conv_call(e, s, dt, c1, x, n, h, w, o1, 1, nullptr, MCG_RES_NONE, 0, 0));
+        snprintf(aname, sizeof(aname), "layer%d.%d.conv1", l + 1, b);
+        audit_tensor(au, aname, o1, (long long)n * h * w * c1.cout);
+      }
       o1_ready = false;
       // f16x3: conv2 -> conv3 (+ downsample / + residual) -> the next block's conv1 as ONE kernel (bneck_x3.hpp)
       const mcg_fused_block* fb = nullptr;
@@ -389,6 +440,12 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
           const int frc = launch_bneck_x3(s, bp, n, fb->cm, fb->nsrc, fb->cn);
           prof_end(rec, s);
           if (frc) { mcg_set_error("bneck_x3 launch failed"); return MCG_ERR_HIP; }
+          snprintf(aname, sizeof(aname), "layer%d.%d.out (fused tail)", l + 1, b);
+          audit_tensor(au, aname, y, (long long)n * h * w * fb->c);
+          if (fb->cn > 0) {
+            snprintf(aname, sizeof(aname), "layer%d.%d.next_conv1 (fused tail)", l + 1, b);
+            audit_tensor(au, aname, o2, (long long)n * h * w * fb->cn);
+          }
           if (fb->cn > 0) { char* tmp = o1; o1 = o2; o2 = tmp; o1_ready = true; }
           x = y; h = ho; w = wo;
           ci = ci_nx;
@@ -396,6 +453,8 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
         }
       }
       MCG_TRY(conv_call(e, s, dt, c2, o1, n, h, w, o2, 1, nullptr, MCG_RES_NONE, 0, 0));
+      snprintf(aname, sizeof(aname), "layer%d.%d.conv2", l + 1, b);
+      audit_tensor(au, aname, o2, (long long)n * ho * wo * c2.cout);
       // conv3 (+ downsample / + residual) together with the NEXT block's conv1 (pw_pair.hpp): layer1 / layer2, where both are
       // HBM-bound.  The next conv1 is the following block's, or the next layer's first (1x1, stride 1 on this block's output).
       const int ci_next = ci + (has_ds ? 4 : 3);
@@ -442,6 +501,8 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
         }
         MCG_TRY(conv_call(e, s, dt, c3, o2, n, ho, wo, y, 1, identity, MCG_RES_ADD, 0, 0));
       }
+      snprintf(aname, sizeof(aname), "layer%d.%d.out", l + 1, b);
+      audit_tensor(au, aname, y, (long long)n * ho * wo * c3.cout);
       x = y; h = ho; w = wo;
       ci += has_ds ? 4 : 3;
     }
@@ -454,11 +515,34 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
     const void* res = i == 3 ? nullptr : t.l[i + 1];
     MCG_TRY(conv_call(e, s, dt, e->lateral[i], t.c[i], n, hs[i], wsz[i], t.l[i], 0, res, res ? MCG_RES_UPSAMPLE_ADD : MCG_RES_NONE,
                       i == 3 ? 0 : hs[i + 1], i == 3 ? 0 : wsz[i + 1]));
+    snprintf(aname, sizeof(aname), "fpn.lateral%d (+ top-down)", i);
+    audit_tensor(au, aname, t.l[i], (long long)n * hs[i] * wsz[i] * 256);
   }
   for (int i = 0; i < 4; ++i) {
     char* dst = (char*)pyr[i] + (size_t)f0 * hs[i] * wsz[i] * 256 * es;
     MCG_TRY(conv_call(e, s, dt, e->fpn_out[i], t.l[i], n, hs[i], wsz[i], dst, 0, nullptr, MCG_RES_NONE, 0, 0));
+    snprintf(aname, sizeof(aname), "fpn.P%d", i + 2);
+    audit_tensor(au, aname, dst, (long long)n * hs[i] * wsz[i] * 256);
   }
+  return MCG_OK;
+}
+
+// Debug read-out of the range audit (engine option range_audit = 1): synchronises the device, copies the counters to the host and
+// resets them.  counts[2 i] = values with |x| > 65504, counts[2 i + 1] = non-finite values of audited tensor i over every frame processed
+// since the last read; names[i] (optional) points at the engine-owned name of tensor i (valid until the option changes).
+extern "C" int mcg_engine_range_audit(mcg_engine* e, unsigned long long* counts, const char** names, int capacity, int* n_out) {
+  MCG_CHECK_ARG(e && counts && n_out && capacity > 0, "mcg_engine_range_audit: bad argument");
+  std::lock_guard<std::mutex> lock(e->mu);
+  if (!e->audit_dev) { mcg_set_error("mcg_engine_range_audit: the range_audit option is off"); return MCG_ERR_ARG; }
+  const int n = (int)e->audit_names.size() < capacity ? (int)e->audit_names.size() : capacity;
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(counts, e->audit_dev, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemset(e->audit_dev, 0, sizeof(unsigned long long) * 2 * mcg_engine::kAuditCap) != hipSuccess) {
+    mcg_set_error("mcg_engine_range_audit: device read failed");
+    return MCG_ERR_HIP;
+  }
+  if (names) for (int i = 0; i < n; ++i) names[i] = e->audit_names[i].c_str();
+  *n_out = n;
   return MCG_OK;
 }
 

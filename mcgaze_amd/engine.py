@@ -231,8 +231,17 @@ class HipEngine:
 
     def set_option(self, name, value):
         """mcg_engine_set_option: 'trunk_streams', 'max_range_frames', 'tile', 'staged_gemm', 'conv3x3_c64', 'stem_fused',
-        'decoder_chain', 'pointwise_pair', 'pointwise_stream', 'bottleneck_fused', 'winograd' (include/mcgaze_hip.h)."""
+        'decoder_chain', 'pointwise_pair', 'pointwise_stream', 'bottleneck_fused', 'winograd', 'range_audit' (include/mcgaze_hip.h)."""
         L.check(self.lib.mcg_engine_set_option(self._handle, name.encode(), int(value)), f'mcg_engine_set_option({name})')
+
+    def range_audit(self, capacity=256):
+        """Read and reset the range audit (set_option('range_audit', 1) first): [(tensor name, values with |x| > 65504, non-finite values)]
+        over every frame the trunk processed since the last read.  mcg_engine_range_audit (a debug call: it synchronises the device)."""
+        counts = (C.c_ulonglong * (2 * capacity))()
+        names = (C.c_char_p * capacity)()
+        n = C.c_int()
+        L.check(self.lib.mcg_engine_range_audit(self._handle, counts, names, capacity, C.byref(n)), 'mcg_engine_range_audit')
+        return [(names[i].decode(), int(counts[2 * i]), int(counts[2 * i + 1])) for i in range(n.value)]
 
     def profile_start(self, capacity=4096):
         L.check(self.lib.mcg_engine_profile_start(self._handle, capacity), 'mcg_engine_profile_start')

@@ -31,7 +31,7 @@ EXPORTS = ['mcg_abi_version', 'mcg_build_id', 'mcg_last_error', 'mcg_device_info
            'mcg_engine_workspace_bytes', 'mcg_trunk_workspace_bytes', 'mcg_decoder_workspace_bytes', 'mcg_backbone_fpn_forward',
            'mcg_decoder_forward', 'mcg_clip_forward', 'mcg_preprocess_frames', 'mcg_engine_set_option', 'mcg_engine_profile_start',
            'mcg_engine_profile_stop', 'mcg_bench_backbone_forward', 'mcg_bottleneck_x3', 'mcg_bench_backbone_levels', 'mcg_conv3x3_wino_x3',
-           'mcg_conv3x3_wino_x3_weight_bytes']
+           'mcg_conv3x3_wino_x3_weight_bytes', 'mcg_engine_range_audit']
 
 
 class ConvDesc(C.Structure):
@@ -119,6 +119,7 @@ def load():
     lib.mcg_bottleneck_x3.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
     lib.mcg_conv3x3_wino_x3.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, C.c_float]
     lib.mcg_conv3x3_wino_x3_weight_bytes.restype = sz
+    lib.mcg_engine_range_audit.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_char_p), i, C.POINTER(i)]
     lib.mcg_conv3x3_wino_x3_weight_bytes.argtypes = [i, i]
     for name in EXPORTS:
         fn = getattr(lib, name)

@@ -37,6 +37,24 @@ def _bn(sd, prefix, c, seed, gamma=(0.5, 1.5)):
     sd[prefix + '.num_batches_tracked'] = np.array(0, dtype=np.int64)
 
 
+def _loguniform(name, seed, shape, lo, hi):
+    return np.exp(_rs(name, seed).uniform(np.log(lo), np.log(hi), shape)).astype(np.float32)
+
+
+def _bn_trained(sd, prefix, conv_key, seed, gamma=(0.03, 3.0)):
+    """BN statistics of the 'trained' weight family: running_var log-uniform over three decades with the conv's ROWS scaled by its square
+    root (so the layer stays calibrated, as a trained BN keeps it: unit variance after normalisation), gamma log-uniform over two decades
+    (a trained net's mix of strong and nearly dead channels) -- the folded weights w * gamma / sigma then span two decades per matrix."""
+    c = sd[conv_key].shape[0]
+    var = _loguniform(prefix + '.running_var', seed, (c,), 0.01, 10.0)
+    sd[conv_key] = (sd[conv_key] * np.sqrt(var)[:, None, None, None]).astype(np.float32)
+    sd[prefix + '.weight'] = _loguniform(prefix + '.weight', seed, (c,), *gamma)
+    sd[prefix + '.bias'] = _normal(prefix + '.bias', seed, (c,), 0.1)
+    sd[prefix + '.running_mean'] = (_normal(prefix + '.running_mean', seed, (c,), 0.1) * np.sqrt(var)).astype(np.float32)
+    sd[prefix + '.running_var'] = var
+    sd[prefix + '.num_batches_tracked'] = np.array(0, dtype=np.int64)
+
+
 def _ln(sd, prefix, c, seed):
     sd[prefix + '.weight'] = _uniform(prefix + '.weight', seed, (c,), 0.5, 1.5)
     sd[prefix + '.bias'] = _normal(prefix + '.bias', seed, (c,), 0.1)
@@ -52,11 +70,18 @@ def _linear(sd, prefix, cout, cin, seed, bias=True, gain=1.0):
         sd[prefix + '.bias'] = _normal(prefix + '.bias', seed, (cout,), 0.1)
 
 
-def make_state_dict(seed=0, depth=50, num_stages=4, d=256, ffn=2048, feat=64, roi=7):
+def make_state_dict(seed=0, depth=50, num_stages=4, d=256, ffn=2048, feat=64, roi=7, family='uniform'):
     """Synthetic weights with the reference detector's ``state_dict`` keys and shapes.
+
+    ``family``: 'uniform' -- every tensor N(0, gain / fan_in), BN terms near one (rounds 1-3); 'trained' -- the statistics of a trained
+    checkpoint where they matter to the arithmetic: He-init convs whose rows and BN sigma spread over three
+    decades, BN gamma over two (folded weights from ~1e-3 to ~1 in one matrix), a small last BN of each block, and box-regression heads
+    small enough that the refined boxes stay inside the frame (a trained detector's boxes sit on heads and faces).
 
     Returns ``dict[str, np.ndarray]`` (float32; ``num_batches_tracked`` int64).
     """
+    assert family in ('uniform', 'trained'), family
+    trained = family == 'trained'
     sd = {}
     # --- backbone (mmdet/models/backbones/resnet.py:369-391, arch table :361-367)
     _conv(sd, 'backbone.conv1.weight', 64, 3, 7, seed)
@@ -76,6 +101,16 @@ def make_state_dict(seed=0, depth=50, num_stages=4, d=256, ffn=2048, feat=64, ro
                 _conv(sd, p + '.downsample.0.weight', planes * 4, inplanes, 1, seed, gain=1.0)
                 _bn(sd, p + '.downsample.1', planes * 4, seed)
             inplanes = planes * 4
+    if trained:   # re-draw every BN of the backbone with the trained statistics (the conv rows are rescaled with them)
+        _bn_trained(sd, 'backbone.bn1', 'backbone.conv1.weight', seed)
+        for li, nblocks in enumerate(ARCH[depth]):
+            for bi in range(nblocks):
+                p = f'backbone.layer{li + 1}.{bi}'
+                _bn_trained(sd, p + '.bn1', p + '.conv1.weight', seed)
+                _bn_trained(sd, p + '.bn2', p + '.conv2.weight', seed)
+                _bn_trained(sd, p + '.bn3', p + '.conv3.weight', seed, gamma=(0.01, 1.0))
+                if bi == 0:
+                    _bn_trained(sd, p + '.downsample.1', p + '.downsample.0.weight', seed)
     # --- FPN (mmdet/models/necks/fpn.py:110-126): conv + bias, no norm, no act
     for i, cin in enumerate((256, 512, 1024, 2048)):
         _conv(sd, f'neck.lateral_convs.{i}.conv.weight', d, cin, 1, seed, gain=1.0)
@@ -113,7 +148,9 @@ def make_state_dict(seed=0, depth=50, num_stages=4, d=256, ffn=2048, feat=64, ro
             _ln(sd, p + f'.reg_fcs.{3 * j + 1}', d, seed)
         for clue in ('face', 'eyes', 'head'):
             _linear(sd, p + f'.{clue}_fc_cls', 1, d, seed)
-            _linear(sd, p + f'.{clue}_fc_reg', 4, d, seed, gain=0.25)
+            _linear(sd, p + f'.{clue}_fc_reg', 4, d, seed, gain=0.01 if trained else 0.25)
+            if trained:
+                sd[p + f'.{clue}_fc_reg.bias'] = (sd[p + f'.{clue}_fc_reg.bias'] * 0.1).astype(np.float32)
         g = f'roi_head.gaze_head.{s}'
         for clue in ('face', 'eyes', 'head'):
             for branch in (f'gaze_{clue}_fcs', f'gaze_{clue}_confidence'):

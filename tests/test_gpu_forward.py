@@ -25,6 +25,7 @@ F32_TOL = 1e-3    # north_star
 BF16_TOL = 0.215
 BF16_TOL_UNUSUAL = 0.32
 CASES = ['clip224', 'clip_nonsquare', 'batch2', 'clip_t5']
+TRAINED_CASES = ['trained_clip224', 'trained_nonsquare_b2']   # synth's 'trained' weight family, goldens from the imported reference
 KEYS = ('gaze_score', 'face_gaze_score', 'eyes_gaze_score', 'head_gaze_score')
 
 
@@ -63,10 +64,19 @@ def engines_by_weights(engines):
 PARITY_ENGINES = ['fp32', 'f16x3']   # both must meet north_star's 1e-3; f16x3 is the one bench.py times as `parity_engine`
 
 
+@pytest.fixture(scope='module')
+def engines_trained():
+    from mcgaze_amd.engine import HipEngine
+    sd = synth.make_state_dict(0, family='trained')
+    return {p: HipEngine(sd, precision=p) for p in ('fp32', 'bf16', 'f16x3')}
+
+
 @pytest.mark.parametrize('precision', PARITY_ENGINES)
-@pytest.mark.parametrize('name', CASES)
-def test_fp32_engine_matches_reference_golden(golden_dir, engines, name, precision):
+@pytest.mark.parametrize('name', CASES + TRAINED_CASES)
+def test_fp32_engine_matches_reference_golden(golden_dir, engines, engines_trained, name, precision):
     g, img, B, T, ishape = load_case(golden_dir, name)
+    if str(g.get('weight_family', 'uniform')) == 'trained':
+        engines = engines_trained
     N = B * T
     hw = np.tile(np.array(ishape[:2], dtype=np.int32), (N, 1))
     out = engines[precision].forward(torch.from_numpy(img).to('cuda:0'), T, img_hw=hw)
@@ -99,6 +109,19 @@ def test_bf16_engine_deviation_is_bounded_not_parity(golden_dir, engines, name):
     ang = torch.rad2deg(torch.acos((gaze[0] * torch.from_numpy(g['gaze_score'])).sum(-1).clamp(-1, 1)))
     print(f'{name} bf16 fused gaze: max |d(yaw,pitch)| = {d.max().item():.2e} rad, mean angular error = {ang.mean().item():.3f} deg')
     assert d.max().item() < BF16_TOL
+
+
+@pytest.mark.parametrize('name', TRAINED_CASES)
+def test_bf16_engine_on_the_trained_weight_family_is_reported(golden_dir, engines_trained, name):
+    """VERDICT r3 item 5c asked whether a 16-bit arithmetic could be parity-grade on REALISTIC boxes (inside the frame, small regression
+    heads): measured here on the 'trained' weight family and printed; bounded loosely (a regression guard), never a parity claim."""
+    g, img, B, T, ishape = load_case(golden_dir, name)
+    hw = np.tile(np.array(ishape[:2], dtype=np.int32), (B * T, 1))
+    out = engines_trained['bf16'].forward(torch.from_numpy(img).to('cuda:0'), T, img_hw=hw)
+    torch.cuda.synchronize()
+    d = orc.yaw_pitch_diff(out['gaze'].cpu()[0], g['gaze_score']).max().item()
+    print(f'{name} bf16 on the trained family: max |d(yaw,pitch)| = {d:.2e} rad (north_star: 1e-3)')
+    assert np.isfinite(d) and d < BF16_TOL_UNUSUAL
 
 
 def test_batched_equals_per_clip_bitwise(engines):
@@ -642,3 +665,31 @@ def test_two_threads_two_engines_one_device(precision):
                                            _ptr(out['scores']), _ptr(self.ws), self.ws.numel()), 'mcg_clip_forward')
             return out
     hammer([_OwnWs(third), _OwnWs(third)])
+
+
+def test_range_audit_counts_values_beyond_the_fp16_range():
+    """the debug option `range_audit` tallies, per activation tensor of the trunk, the values an f16x3 operand half
+    cannot hold (|x| > 65504) and the non-finite ones.  The synthetic net is clean (all zeros); the same net with its stem conv scaled by
+    1e6 trips the counter at the first tensor and -- the halves saturate instead of overflowing -- stays finite after it."""
+    from mcgaze_amd.engine import HipEngine
+    sd = synth.make_state_dict(0)
+    img = torch.from_numpy(synth.make_clips(3, 2, 7)).to('cuda:0')
+    e = HipEngine(sd, precision='f16x3')
+    e.set_option('range_audit', 1)
+    e.forward(img, 7)
+    rec = e.range_audit()
+    names = [r[0] for r in rec]
+    assert names[0] == 'stem' and 'fpn.P2' in names and any(n.startswith('layer3.5') for n in names) and len(rec) > 40
+    assert all(big == 0 and bad == 0 for _, big, bad in rec), [r for r in rec if r[1] or r[2]][:4]
+    hot = dict(sd)
+    hot['backbone.conv1.weight'] = sd['backbone.conv1.weight'] * 1e6
+    e2 = HipEngine(hot, precision='f16x3')
+    e2.set_option('range_audit', 1)
+    out = e2.forward(img, 7)
+    rec2 = e2.range_audit()
+    assert rec2[0][0] == 'stem' and rec2[0][1] > 1000 and rec2[0][2] == 0, rec2[:3]
+    assert sum(r[2] for r in rec2) == 0 and bool(torch.isfinite(out['gaze']).all())   # saturating halves: large, never inf / nan
+    assert all(r[1] == 0 and r[2] == 0 for r in e2.range_audit())                     # the read resets the counters
+    e2.set_option('range_audit', 0)
+    with pytest.raises(Exception, match='range_audit option is off'):
+        e2.range_audit()

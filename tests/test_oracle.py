@@ -10,7 +10,7 @@ import torch
 from mcgaze_amd import synth
 from oracle import mcgaze_oracle as orc
 
-CASES = ['clip224', 'clip_nonsquare', 'batch2', 'clip_t5']
+CASES = ['clip224', 'clip_nonsquare', 'batch2', 'clip_t5', 'trained_clip224', 'trained_nonsquare_b2']   # trained_*: synth's 'trained' weight family
 
 
 def load_case(golden_dir, name):
@@ -30,9 +30,16 @@ def weights():
     return orc.as_torch(synth.make_state_dict(0))
 
 
+@pytest.fixture(scope='module')
+def weights_trained():
+    return orc.as_torch(synth.make_state_dict(0, family='trained'))
+
+
 @pytest.mark.parametrize('name', CASES)
-def test_forward_matches_reference_golden(golden_dir, weights, name):
+def test_forward_matches_reference_golden(golden_dir, weights, weights_trained, name):
     g, img, metas, T = load_case(golden_dir, name)
+    if str(g.get('weight_family', 'uniform')) == 'trained':
+        weights = weights_trained
     col = []
     det, gaze = orc.forward(weights, img, metas, T, rescale=bool(g['rescale']), collect=col)
     for k in ('gaze_score', 'face_gaze_score', 'eyes_gaze_score', 'head_gaze_score'):

@@ -1,6 +1,6 @@
 """GPU tool: parity fuzz of the engines against the CPU oracle on random shapes -- clip length, batch, frame size (multiples of 32),
 per-frame img_shape inside the padded frame, weight seed -- to look for inputs where the parity-grade engines leave north_star's
-1e-3 rad on (yaw, pitch).  usage: python tools/parity_fuzz.py [cases=24] [seed=0] [precisions=f16x3,fp32] [diagnose=1]"""
+1e-3 rad on (yaw, pitch).  usage: python tools/parity_fuzz.py [cases=24] [seed=0] [precisions=f16x3,fp32] [diagnose=1] [family=uniform|trained]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,6 +15,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 precs = (sys.argv[3] if len(sys.argv) > 3 else 'f16x3,fp32').split(',')
 diagnose = (sys.argv[4] if len(sys.argv) > 4 else '1') != '0'
+family = sys.argv[5] if len(sys.argv) > 5 else 'uniform'   # synth.make_state_dict's weight family
 torch.set_num_threads(16)
 engines, sds = {}, {}
 worst = {p: 0.0 for p in precs}
@@ -27,7 +28,7 @@ for c in range(cases):
     wseed, B, T, H, W, (ih, iw), full, img, metas = k['wseed'], k['B'], k['T'], k['H'], k['W'], k['img_shape'], k['full'], k['img'], k['metas']
     N = B * T
     if wseed not in sds:
-        sds[wseed] = synth.make_state_dict(wseed)
+        sds[wseed] = synth.make_state_dict(wseed, family=family)
     stages = []
     _, ref = orc.forward(sds[wseed], img, metas, T, collect=stages)
     want = orc.yaw_pitch(ref['gaze_score'])
