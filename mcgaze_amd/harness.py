@@ -100,17 +100,29 @@ def _run_windows(engine, ids, plans, get_window, batch_clips, person_threshold):
     pending = [len(p) for p in plans]
     records = [None] * len(plans)
 
+    keep = []                                          # pinned host tensors of the last flush: alive until their non-blocking copies ran
+
+    def upload(t):
+        # small per-batch tables (img_shape, scale_factor): pinned + non-blocking, so that the host does not wait for the device queue to
+        # drain (a pageable .to() did: the host then idled for the previous batch's forward instead of preparing the next)
+        if dev.type != 'cuda':
+            return t.to(dev)
+        p = t.pin_memory()
+        keep.append(p)
+        return p.to(dev, non_blocking=True)
+
     def flush(key):
         items = buckets.pop(key, [])
         if not items:
             return
         T = key[0]
         x = torch.cat([it[2] for it in items]).to(dev, torch.float32).contiguous()
-        hw = None if items[0][3] is None else torch.cat([torch.as_tensor(it[3], dtype=torch.int32).reshape(-1, 2) for it in items]).numpy()
+        del keep[:max(0, len(keep) - 4)]
+        hw = None if items[0][3] is None else upload(torch.cat([torch.as_tensor(it[3], dtype=torch.int32).reshape(-1, 2) for it in items]))
         out = engine.forward(x, T, img_hw=hw)
         boxes = out['boxes']
         if items[0][4] is not None:   # rescale=True: every frame's boxes by its own scale_factor (multiclue_gaze_roi_head.py:360-363)
-            boxes = boxes / torch.cat([torch.as_tensor(it[4], dtype=torch.float32) for it in items]).to(dev)[:, None, :]
+            boxes = boxes / upload(torch.cat([torch.as_tensor(it[4], dtype=torch.float32) for it in items]))[:, None, :]
         det = torch.cat([boxes, out['scores'][..., None]], dim=-1)
         for bi, (vi, wi, _, _, _) in enumerate(items):
             sl = slice(bi * T, (bi + 1) * T)
@@ -149,7 +161,8 @@ def run_videos(engine, videos, clip_len=7, stride=4, batch_clips=64, scale_facto
     return _run_windows(engine, [v['id'] for v in videos], plans, get_window, batch_clips, person_threshold)
 
 
-def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_clips=64, person_threshold=0.5, rng=None, workers=0, lookahead=None):
+def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_clips=64, person_threshold=0.5, rng=None, workers=0, lookahead=None,
+                   processes=False):
     """tools/test_gaze360_gaze.py:57-269 from the annotation file down: for every ``anno['videos']`` entry (``id``,
     ``file_names``) each window's frames are loaded and preprocessed ANEW through ``pipeline`` (a
     mcgaze_amd.pipeline.DevicePipeline built from cfg.data.test.pipeline) -- like the reference, which re-runs its test
@@ -159,7 +172,8 @@ def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_cli
     Each file is decoded once while it stays cached (windows overlap by three frames); windows are preprocessed in groups (one
     pinned copy and one launch per padded size).  ``workers`` > 0 adds host threads that decode ``lookahead`` windows ahead of the
     consumer (the reference uses 7 loader threads per window, :88-95) -- measured slower than in-line decoding for small frames
-    (pipeline.FrameCache), hence 0 by default.  The records do not depend on either."""
+    (pipeline.FrameCache), hence 0 by default; ``processes=True`` makes them helper PROCESSES that decode into a shared-memory ring (no
+    interpreter lock in common with this loop).  The records do not depend on any of it."""
     import numpy as np
     import os
     from .pipeline import FrameCache
@@ -170,7 +184,7 @@ def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_cli
     pos = {vw: i for i, vw in enumerate(order)}
     lookahead = 2 * batch_clips if lookahead is None else lookahead
     group = max(1, min(batch_clips, 32))                                    # windows staged per preprocessing call
-    cache = FrameCache(workers, capacity=((lookahead if workers > 0 else 0) + group + 2) * clip_len)   # in-line decoding never runs ahead: only the staged group (and the 3-frame overlap) is worth keeping
+    cache = FrameCache(workers, capacity=((lookahead if workers > 0 else 0) + group + 2) * clip_len, processes=processes)   # in-line decoding never runs ahead: only the staged group (and the 3-frame overlap) is worth keeping
     state = dict(ahead=0)
 
     def names_of(vi, wi):

@@ -69,6 +69,54 @@ class LoadImageFromFile:
         pass
 
 
+class _DecodeProcs:
+    """``n`` decode helper processes (mcgaze_amd/_decode_worker.py) fed over their stdin, one reader thread per process turning answer lines
+    into Futures.  A request goes to the process with the shortest queue."""
+
+    def __init__(self, n, ring_path, slot_bytes):
+        import subprocess
+        import sys
+        worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_decode_worker.py')
+        self.procs = [subprocess.Popen([sys.executable, worker, ring_path, str(slot_bytes)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                       text=True, bufsize=1) for _ in range(n)]
+        self.pending = [collections.deque() for _ in range(n)]
+        self.threads = [threading.Thread(target=self._reader, args=(k,), daemon=True, name=f'mcg-decode-{k}') for k in range(n)]
+        for t in self.threads:
+            t.start()
+
+    def _reader(self, k):
+        for line in self.procs[k].stdout:
+            fut = self.pending[k].popleft()
+            head, _, rest = line.rstrip('\n').partition(' ')
+            if head == '-1':
+                fut.set_exception(RuntimeError(f'decode worker: {rest}'))
+            else:
+                fut.set_result((int(head), int(rest)))
+        while self.pending[k]:                                   # the process went away with requests outstanding
+            self.pending[k].popleft().set_exception(RuntimeError('decode worker exited'))
+
+    def submit(self, path, offset):
+        if '\n' in path:
+            raise ValueError('file names with newlines cannot go to the decode workers')
+        k = min(range(len(self.procs)), key=lambda i: len(self.pending[i]))
+        fut = concurrent.futures.Future()
+        self.pending[k].append(fut)
+        self.procs[k].stdin.write(f'{offset} {path}\n')
+        return fut
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except OSError:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:
+                p.kill()
+
+
 class FrameCache:
     """Decoded frames by path: each file is decoded once while it stays cached (LRU), optionally ahead of the consumer.
 
@@ -76,45 +124,108 @@ class FrameCache:
     tools/test_gaze360_gaze.py:88-100).  Here a decode is shared by the windows that use the frame.  With ``workers`` > 0 a pool of
     host threads decodes what ``prefetch`` names ahead of the consumer (the reference uses seven loader threads); measured on the
     GPU box this LOSES to in-line decoding for small frames (a 360x360 JPEG decodes in 0.5 ms; the threads contend with the
-    consumer for the interpreter lock and the allocator), so the default is in-line.  Only the DECODE is shared: crop draws, geometry
-    and the pixel kernel still run per window, in the caller's order -- results do not depend on the cache or the thread count."""
+    consumer for the interpreter lock and the allocator), so the default is in-line.  ``processes=True`` (round 4) decodes in ``workers``
+    helper PROCESSES instead (``_decode_worker.py``, plain children started with subprocess: a process that holds a HIP context is
+    not forked -- measured: forked workers made every later host -> device copy of the parent 58 ms slow -- and the caller's main
+    module is not re-imported) that write the RGB pixels into a memory-mapped ring file in /dev/shm of ``capacity`` slots (``slot_bytes``
+    each; a larger frame is decoded in line); the consumer gets numpy views of the ring (valid while the frame stays cached: run_many
+    copies them into its pinned staging buffer at once).
+    Only the DECODE is shared: crop draws, geometry and the pixel kernel still run per window, in the caller's order -- results do
+    not depend on the cache, the worker count or the worker kind."""
 
-    def __init__(self, workers=0, capacity=512, loader=None):
+    def __init__(self, workers=0, capacity=512, loader=None, processes=False, slot_bytes=3 << 20):
         self.rgb = loader is None                   # our own decode keeps the decoder's RGB order (DevicePipeline.run_many swaps in the kernel)
         self.loader = loader or (lambda path: LoadImageFromFile.load(path, rgb=True))
         self.capacity = max(int(capacity), 1)
-        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix='mcg-decode') if workers > 0 else None
-        self.items = collections.OrderedDict()      # path -> Future (pool) or array (in line), least recently used first
+        self.ring, self.ring_path, self.procs, self.free, self.slot_bytes = None, None, None, [], int(slot_bytes)
+        self.pool = None
+        if workers > 0 and processes:
+            if loader is not None:
+                raise ValueError('FrameCache(processes=True) decodes with its own worker (PIL, RGB)')
+            import tempfile
+            fd, self.ring_path = tempfile.mkstemp(prefix='mcg_ring_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+            os.ftruncate(fd, (self.capacity + 1) * self.slot_bytes)
+            os.close(fd)
+            self.ring = np.memmap(self.ring_path, dtype=np.uint8, mode='r+')
+            self.free = list(range(self.capacity + 1))
+            self.procs = _DecodeProcs(int(workers), self.ring_path, self.slot_bytes)
+        elif workers > 0:
+            self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix='mcg-decode')
+        self.items = collections.OrderedDict()      # path -> Future (threads) / (Future, ring slot) (processes) / array (in line), least recently used first
+        self.used = collections.OrderedDict()       # paths the consumer has already asked for, oldest use first: the eviction candidates
         self.lock = threading.Lock()
         self.decodes = 0
 
     def _entry(self, path, wanted_now):
         with self.lock:
             e = self.items.get(path)
+            if wanted_now:
+                self.used[path] = True
+                self.used.move_to_end(path)
             if e is not None:
                 self.items.move_to_end(path)
                 return e
-            if self.pool is None and not wanted_now:
+            if self.pool is None and self.procs is None and not wanted_now:
                 return None                         # in-line mode: prefetch is a no-op, the decode happens when the frame is asked for
-            e = self.items[path] = self.pool.submit(self.loader, path) if self.pool is not None else self.loader(path)
+            if self.procs is not None:
+                while len(self.items) >= self.capacity:          # make room first: the new decode needs a ring slot
+                    self._evict()
+                slot = self.free.pop()
+                e = self.items[path] = (self.procs.submit(path, slot * self.slot_bytes), slot)
+            else:
+                e = self.items[path] = self.pool.submit(self.loader, path) if self.pool is not None else self.loader(path)
             self.decodes += 1
             while len(self.items) > self.capacity:
-                self.items.popitem(last=False)
+                self._evict()
             return e
 
+    def _evict(self):
+        # A frame decoded AHEAD and not yet asked for is the one the consumer needs next: plain LRU threw exactly those out (they are the
+        # oldest entries once the cache is full -- every prefetch then cost a second, synchronous decode: round 3's "threads are slower").
+        # Victims are frames already consumed, oldest use first; an unconsumed one only when nothing else is left.
+        victim = None
+        while self.used and victim is None:
+            p, _ = self.used.popitem(last=False)
+            if p in self.items:
+                victim = p
+        old = self.items.pop(victim) if victim is not None else self.items.popitem(last=False)[1]
+        if isinstance(old, tuple):                               # ring slot: its writer must be done before the slot is handed out again
+            try:
+                old[0].result()
+            except Exception:
+                pass
+            self.free.append(old[1])
+
     def prefetch(self, paths):
-        if self.pool is not None:
+        if self.pool is not None or self.procs is not None:
             for p in paths:
                 self._entry(p, False)
 
     def __call__(self, path):
         e = self._entry(path, True)
+        if isinstance(e, tuple):                                 # decoded by a helper process into ring slot e[1]
+            h, w = e[0].result()
+            if h == 0:
+                return self.loader(path)                         # larger than a slot: decoded here
+            o = e[1] * self.slot_bytes
+            return self.ring[o:o + h * w * 3].reshape(h, w, 3)
         return e.result() if isinstance(e, concurrent.futures.Future) else e
 
     def close(self):
         if self.pool is not None:
             self.pool.shutdown(wait=False, cancel_futures=True)
+        if self.procs is not None:
+            self.procs.close()
+            self.procs = None
         self.items.clear()
+        self.used.clear()
+        if self.ring_path is not None:
+            self.ring = None
+            try:
+                os.unlink(self.ring_path)
+            except OSError:
+                pass
+            self.ring_path = None
 
 
 @PIPELINES.register_module()
@@ -342,36 +453,65 @@ class DevicePipeline:
             rgb_source = rgb_source and bool(getattr(loader, 'rgb', False))
         else:
             load = (lambda path: LoadImageFromFile.load(path, rgb=True)) if rgb_source else LoadImageFromFile.load
-        arrays, plans, bounds = [], [], [0]
+        # arrays: the DISTINCT decoded frames of this call (a file named by several windows -- they overlap by three frames -- is staged and
+        # uploaded once); src[k]: the array the k-th (window, frame) reads; plans stay per (window, frame): every use draws its own crop
+        arrays, src, plans, bounds, seen = [], [], [], [0], {}
         for frames in windows:
             for f in frames:
                 if isinstance(f, str):
                     path = os.path.join(img_prefix, f) if img_prefix is not None else f
-                    arr, names = load(path), (path, f)
-                    if not rgb_source and getattr(loader, 'rgb', False):
-                        arr = np.ascontiguousarray(arr[..., ::-1])           # mixed with caller-supplied BGR arrays: one order per call
+                    k = seen.get(path)
+                    if k is None:
+                        arr = load(path)
+                        if not rgb_source and getattr(loader, 'rgb', False):
+                            arr = np.ascontiguousarray(arr[..., ::-1])       # mixed with caller-supplied BGR arrays: one order per call
+                        k = seen[path] = len(arrays)
+                        arrays.append(arr)
+                    arr, names = arrays[k], (path, f)
                 else:
                     arr, names = np.ascontiguousarray(f), (None, None)
+                    k = len(arrays)
+                    arrays.append(arr)
                 if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
                     raise TypeError(f'frames must be HxWx3 uint8 arrays, got {arr.dtype} {arr.shape}')
-                arrays.append(arr)
+                src.append(k)
                 plans.append(self.plan(arr.shape, rng, *names))
-            bounds.append(len(arrays))
+            bounds.append(len(src))
         out = [None] * len(windows)
-        n = len(arrays)
+        n = len(src)
         for wi in range(len(windows)):
             if bounds[wi] == bounds[wi + 1]:
                 out[wi] = (torch.empty(0, 3, 0, 0, dtype=torch.float32, device=dev), [])
         if n == 0:
             return out
         offs = np.cumsum([0] + [(a.size + 255) // 256 * 256 for a in arrays])
+        # the frame descriptors travel in the same pinned staging buffer, behind the pixels: one non-blocking copy for everything (a
+        # pageable .to() per descriptor table blocked the host until the stream had drained -- the engine's previous batch)
+        groups = {}                                           # padded size -> windows
+        for wi in range(len(windows)):
+            a, b = bounds[wi], bounds[wi + 1]
+            if b > a:
+                pad = (max(p.pad_shape[0] for p in plans[a:b]), max(p.pad_shape[1] for p in plans[a:b]))
+                groups.setdefault(pad, []).append(wi)
+        dsz = C.sizeof(L.FrameDesc)
+        desc_off, total = {}, int(offs[-1])
+        for pad, wis in groups.items():
+            desc_off[pad] = total
+            total += (sum(bounds[wi + 1] - bounds[wi] for wi in wis) * dsz + 255) // 256 * 256
         with torch.cuda.device(dev):
-            slot, host = self._staging(int(offs[-1]), dev)
+            slot, host = self._staging(total, dev)
             host_np = host.numpy()
             for a, o in zip(arrays, offs):
                 host_np[int(o):int(o) + a.size] = a.reshape(-1)
-            raw = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)
-            raw.copy_(host[:int(offs[-1])], non_blocking=True)
+            raw = torch.empty(total, dtype=torch.uint8, device=dev)
+            for pad, wis in groups.items():
+                idx = [k for wi in wis for k in range(bounds[wi], bounds[wi + 1])]
+                desc = (L.FrameDesc * len(idx))()
+                for i, k in enumerate(idx):
+                    a, p = arrays[src[k]], plans[k]
+                    desc[i] = L.FrameDesc(raw.data_ptr() + int(offs[src[k]]), a.shape[0], a.shape[1], a.shape[1] * 3, *p.crop, p.img_shape[0], p.img_shape[1])
+                host_np[desc_off[pad]:desc_off[pad] + len(idx) * dsz] = np.frombuffer(desc, dtype=np.uint8)
+            raw.copy_(host[:total], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             self._pin_ev[slot] = ev
@@ -379,25 +519,13 @@ class DevicePipeline:
         mean = (C.c_float * 3)(*[float(v) for v in norm['mean']])
         stdinv = (C.c_float * 3)(*[float(np.float32(1.0 / np.float64(v))) for v in norm['std']])
         swap = int(bool(norm['to_rgb']) != rgb_source)        # channel swap the kernel performs: wanted order differs from the source's
-        groups = {}                                           # padded size -> windows
-        for wi in range(len(windows)):
-            a, b = bounds[wi], bounds[wi + 1]
-            if b > a:
-                pad = (max(p.pad_shape[0] for p in plans[a:b]), max(p.pad_shape[1] for p in plans[a:b]))
-                groups.setdefault(pad, []).append(wi)
         keep = [raw]
         s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         for (pad_h, pad_w), wis in groups.items():
-            idx = [k for wi in wis for k in range(bounds[wi], bounds[wi + 1])]
-            desc = (L.FrameDesc * len(idx))()
-            for i, k in enumerate(idx):
-                a, p = arrays[k], plans[k]
-                desc[i] = L.FrameDesc(raw.data_ptr() + int(offs[k]), a.shape[0], a.shape[1], a.shape[1] * 3, *p.crop, p.img_shape[0], p.img_shape[1])
-            desc_dev = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(dev)
-            img = torch.empty(len(idx), 3, pad_h, pad_w, dtype=torch.float32, device=dev)
-            L.check(lib.mcg_preprocess_frames(C.c_void_p(s), C.c_void_p(desc_dev.data_ptr()), len(idx), C.c_void_p(img.data_ptr()), pad_h, pad_w,
+            n_idx = sum(bounds[wi + 1] - bounds[wi] for wi in wis)
+            img = torch.empty(n_idx, 3, pad_h, pad_w, dtype=torch.float32, device=dev)
+            L.check(lib.mcg_preprocess_frames(C.c_void_p(s), C.c_void_p(raw.data_ptr() + desc_off[(pad_h, pad_w)]), n_idx, C.c_void_p(img.data_ptr()), pad_h, pad_w,
                                               mean, stdinv, swap), 'mcg_preprocess_frames')
-            keep.append(desc_dev)
             at = 0
             for wi in wis:
                 cnt = bounds[wi + 1] - bounds[wi]
