@@ -162,7 +162,7 @@ def run_videos(engine, videos, clip_len=7, stride=4, batch_clips=64, scale_facto
 
 
 def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_clips=64, person_threshold=0.5, rng=None, workers=0, lookahead=None,
-                   processes=False):
+                   processes=False, video_rng=None):
     """tools/test_gaze360_gaze.py:57-269 from the annotation file down: for every ``anno['videos']`` entry (``id``,
     ``file_names``) each window's frames are loaded and preprocessed ANEW through ``pipeline`` (a
     mcgaze_amd.pipeline.DevicePipeline built from cfg.data.test.pipeline) -- like the reference, which re-runs its test
@@ -173,7 +173,11 @@ def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_cli
     pinned copy and one launch per padded size).  ``workers`` > 0 adds host threads that decode ``lookahead`` windows ahead of the
     consumer (the reference uses 7 loader threads per window, :88-95) -- measured slower than in-line decoding for small frames
     (pipeline.FrameCache), hence 0 by default; ``processes=True`` makes them helper PROCESSES that decode into a shared-memory ring (no
-    interpreter lock in common with this loop).  The records do not depend on any of it."""
+    interpreter lock in common with this loop).  The records do not depend on any of it.
+    ``video_rng``: video id -> numpy RandomState.  With it every video draws its crops from its OWN generator (created when its first
+    window is planned) instead of the shared ``rng``: the records then do not depend on which videos a process was given or in what
+    order -- what a run sharded over several consumer processes needs to reproduce a single-process run record for record (the
+    reference's single global generator makes its results depend on the shard layout)."""
     import numpy as np
     import os
     from .pipeline import FrameCache
@@ -192,6 +196,14 @@ def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_cli
         return sorted(videos[vi]['file_names'][a:b])
 
     staged = {}
+    per_video = {}
+
+    def rng_of(vi):
+        if video_rng is None:
+            return rng
+        if vi not in per_video:
+            per_video[vi] = video_rng(videos[vi]['id'])
+        return per_video[vi]
 
     def get_window(vi, wi):
         i = pos[(vi, wi)]
@@ -204,7 +216,7 @@ def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_cli
                     v2, w2 = order[state['ahead']]
                     cache.prefetch(os.path.join(root, n) if root is not None else n for n in names_of(v2, w2))
                     state['ahead'] += 1
-            res = pipeline.run_many([names_of(v2, w2) for v2, w2 in todo], device=engine.device, rng=rng, img_prefix=root, loader=cache)
+            res = pipeline.run_many([names_of(v2, w2) for v2, w2 in todo], device=engine.device, rng=[rng_of(v2) for v2, _ in todo], img_prefix=root, loader=cache)
             staged.update({i + k: r for k, r in enumerate(res)})
         img, metas = staged.pop(i)
         hw = [m['img_shape'][:2] for m in metas]

@@ -456,7 +456,10 @@ class DevicePipeline:
         # arrays: the DISTINCT decoded frames of this call (a file named by several windows -- they overlap by three frames -- is staged and
         # uploaded once); src[k]: the array the k-th (window, frame) reads; plans stay per (window, frame): every use draws its own crop
         arrays, src, plans, bounds, seen = [], [], [], [0], {}
-        for frames in windows:
+        rngs = rng if isinstance(rng, (list, tuple)) else [rng] * len(windows)   # one generator per window (harness: one per VIDEO), or one for all
+        if len(rngs) != len(windows):
+            raise ValueError(f'run_many: {len(rngs)} generators for {len(windows)} windows')
+        for frames, rng in zip(windows, rngs):
             for f in frames:
                 if isinstance(f, str):
                     path = os.path.join(img_prefix, f) if img_prefix is not None else f

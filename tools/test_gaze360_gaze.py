@@ -51,6 +51,8 @@ def parse_args(argv=None):
                     help="'f16x3' (default): parity-grade fast engine; 'fp32': exact reference mode; 'bf16': throughput mode (not within the 1e-3 tolerance)")
     ap.add_argument('--batch-clips', type=int, default=64)
     ap.add_argument('--seed', type=int, default=None)
+    ap.add_argument('--per-video-seed', action='store_true',
+                    help='seed the crop draws per VIDEO (seed + video id) instead of one generator per process: the records then do not depend on the number of ranks')
     ap.add_argument('--workers', type=int, default=8, help='decode helpers that run ahead of the GPU (0 = decode in line); 8 processes measured 3 430 frames/s against 1 500 in line')
     ap.add_argument('--decode', default='processes', choices=['processes', 'threads'], help="kind of decode helper: child processes writing into a /dev/shm ring (default), or host threads")
     ap.add_argument('--ranks-per-gpu', type=int, default=1, help='with torch.distributed.run: consecutive ranks that share one GPU (the consumer loop of one process feeds ~3 400 frames/s; the engine takes five times that)')
@@ -85,7 +87,8 @@ def main(argv=None):
     idx = shard_videos(anno['videos'], world, rank)
     rng = np.random.RandomState(a.seed + rank) if a.seed is not None else None
     recs = harness.run_annotation(model.engine(), dict(videos=[anno['videos'][i] for i in idx]), a.root, pipe, batch_clips=a.batch_clips, rng=rng, workers=a.workers,
-                                  processes=a.decode == 'processes')
+                                  processes=a.decode == 'processes',
+                                  video_rng=(lambda vid: np.random.RandomState(((a.seed or 0) * 1000003 + int(vid)) & 0x7fffffff)) if a.per_video_seed else None)
     if world > 1:
         recs = gather_records(idx, recs, len(anno['videos']))
     if rank == 0:
