@@ -21,12 +21,26 @@ w = (torch.randn(Cout, k, k, Cin, device='cuda') / (Cin * k * k) ** 0.5).to(dt)
 b = torch.randn(Cout, device='cuda')
 Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
 r = torch.randn(N, Ho, Wo, Cout, device='cuda').to(dt) if res else None
+if split:   # pack once (engine.conv2d packs per call: fine for tests, not for timing), then drive the C-ABI directly
+    import ctypes as C
+    from mcgaze_amd import lib as L
+    from mcgaze_amd.packing import pow2_prescale, split_pack
+    lib = L.load()
+    ws, wscale = pow2_prescale(w.reshape(Cout, -1).cpu())
+    wp = split_pack(ws).cuda()
+    y = torch.empty(N, Ho, Wo, Cout, device='cuda')
+    d = L.ConvDesc(x.data_ptr(), wp.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, y.data_ptr(), N, H, W, Cin, Cout, k, k, stride, pad, 1,
+                   1 if res else 0, 0, 0, None, 0, 1, 0, 0, tile, 0, wscale)
+    s_ = E._stream()
+    run = lambda: L.check(lib.mcg_conv2d(s_, L.MCG_F16X3, C.byref(d)), 'mcg_conv2d')
+else:
+    run = lambda: E.conv2d(x, w, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1 if res else 0, tile=tile)
 for _ in range(60):
-    y = E.conv2d(x, w, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1 if res else 0, tile=tile, split=split)
+    run()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(iters):
-    y = E.conv2d(x, w, b, stride=stride, pad=pad, relu=True, residual=r, residual_mode=1 if res else 0, tile=tile, split=split)
+    run()
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / iters * 1e3
 fl = 2.0 * N * Ho * Wo * Cout * Cin * k * k
