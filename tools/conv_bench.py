@@ -8,7 +8,7 @@ N, H, W, Cin, Cout, k, stride, pad = [int(v) for v in sys.argv[1:9]]
 iters = int(sys.argv[9]) if len(sys.argv) > 9 else 50
 res = int(sys.argv[10]) if len(sys.argv) > 10 else 0
 tile = int(sys.argv[11]) if len(sys.argv) > 11 else 0
-prec = sys.argv[12] if len(sys.argv) > 12 else 'bf16'
+prec = sys.argv[12] if len(sys.argv) > 12 else 'f16x3'
 mode = sys.argv[13] if len(sys.argv) > 13 else 'randn'   # the rate depends on the operand bits: the kernel sits on the package power cap
 dt = torch.bfloat16 if prec == 'bf16' else torch.float32
 split = prec == 'f16x3'

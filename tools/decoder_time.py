@@ -5,7 +5,7 @@ import torch
 from mcgaze_amd import lib as L, synth
 from mcgaze_amd.engine import HipEngine, _ptr, _ws, _stream
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-prec = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
+prec = sys.argv[2] if len(sys.argv) > 2 else 'f16x3'   # the product engine; 'bf16' = the throughput mode
 e = HipEngine(synth.make_state_dict(0), precision=prec)
 img = torch.from_numpy(synth.make_clips(3, 64, 7)).cuda()
 N, T, H, W = img.shape[0], 7, 224, 224

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mcgaze_amd import synth
 from mcgaze_amd.engine import HipEngine
-e = HipEngine(synth.make_state_dict(0), precision='bf16')
+PREC = next((a for a in sys.argv[1:] if a in ('f16x3', 'bf16', 'fp32')), 'f16x3')   # the product engine unless another is named
+e = HipEngine(synth.make_state_dict(0), precision=PREC)
 img = torch.from_numpy(synth.make_clips(3, 64, 7)).cuda()
 out = dict(gaze=torch.empty(4, 448, 3, device='cuda'), boxes=torch.empty(448, 3, 4, device='cuda'), scores=torch.empty(448, 3, device='cuda'))
 def direct(iters=20):

@@ -7,7 +7,7 @@ from mcgaze_amd import lib as L, synth
 from mcgaze_amd.engine import HipEngine
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-prec = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
+prec = sys.argv[2] if len(sys.argv) > 2 else 'f16x3'   # the product engine; 'bf16' = the throughput mode
 eng = HipEngine(synth.make_state_dict(0), precision=prec)
 eng.set_option('trunk_streams', 1)
 if len(sys.argv) > 3:

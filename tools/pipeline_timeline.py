@@ -7,7 +7,8 @@ import torch
 from mcgaze_amd import synth, lib as L
 from mcgaze_amd.engine import HipEngine, PipelinedRunner, _ptr
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-e = HipEngine(synth.make_state_dict(0), precision='bf16')
+PREC = next((a for a in sys.argv[1:] if a in ('f16x3', 'bf16', 'fp32')), 'f16x3')   # the product engine unless another is named
+e = HipEngine(synth.make_state_dict(0), precision=PREC)
 B, T = 64, 7
 img = torch.from_numpy(synth.make_clips(3, B, T)).cuda()
 r = PipelinedRunner(e, B * T, 224, 224, T)

@@ -6,7 +6,7 @@ import torch
 from mcgaze_amd import synth
 from mcgaze_amd.engine import HipEngine
 
-prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+prec = sys.argv[1] if len(sys.argv) > 1 else 'f16x3'   # the product engine; 'bf16' = the throughput mode
 eng = HipEngine(synth.make_state_dict(0), precision=prec)
 img = torch.from_numpy(synth.make_clips(3, 64, 7)).cuda()
 for streams in (1, 2, 3, 4):
