@@ -103,6 +103,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the cpu_baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--latency', type=int, default=1, choices=[0, 1], help='1: report single-clip latency (rank 0, N=1 only)')
     ap.add_argument('--host-input-steps', type=int, default=20, help='timed steps of the host_input leg (rank 0, N=1 only; 0 disables)')
+    ap.add_argument('--engine-option', action='append', default=[], metavar='NAME=INT',
+                    help='mcg_engine_set_option on every engine of the run (A/B of a kernel variant, e.g. winograd=2); recorded in config.engine_options')
     ap.add_argument('--fake-engine', action='store_true',
                     help='a CPU stand-in engine + gloo instead of HipEngine + RCCL: executes THIS FILE\'s N > 1 control flow (clip sharding, '
                          'fused exchange, ring-neighbour check, strong-scaling leg, stdout hand-over) in a container without GPUs '
@@ -229,6 +231,9 @@ class Leg:
             from mcgaze_amd.engine import HipEngine
             self.eng = HipEngine(synth.make_state_dict(0), precision=precision, device=dev)
         self.eng.set_option('trunk_streams', a.trunk_streams)
+        for kv in a.engine_option:
+            name, _, val = kv.partition('=')
+            self.eng.set_option(name, int(val))
         self.gathers = [ResultGather(self.N, world, dev) for _ in range(2)]   # results double-buffered like the pipeline
         self.outs = [g.local_views() for g in self.gathers]                    # the engine writes straight into the fused exchange buffers
         self.runner = None
@@ -762,7 +767,7 @@ def main():
                        'engine': WHAT[a.precision],
                        'parallelism': f'dp{world} (clips sharded by rank, one fused all_gather of results per step)' if world > 1 else 'single GPU',
                        'batch_pipeline': 'decoder(step k) overlaps trunk(step k+1) on a second HIP stream; the loop submits from the trunk stream; all K batches complete inside the timed region' if (a.pipeline and a.workload == 'full') else 'none (serial)',
-                       'trunk_streams': a.trunk_streams},
+                       'trunk_streams': a.trunk_streams, 'engine_options': a.engine_option},
             'world_size': dist.get_world_size() if dist is not None else 1,
             'timed_region_s': head['timed_region_s'],
             'verified': head['verified'],

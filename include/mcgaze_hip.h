@@ -116,10 +116,12 @@ int mcg_bottleneck_x3(mcg_stream s, const float* x, const float* src2, const voi
  * input; MCG_ERR_UNSUPPORTED otherwise (use mcg_conv2d).  The result differs from mcg_conv2d's in rounding only (both within 1e-6 of
  * scale of the f64 convolution); it does not depend on how the frames are batched.  tile: 0 = chosen by grid size; 1 / 2 / 3 force the
  * 128 x 128 / 64 x 64 / 32 x 64 (pairs x channels) workgroup tile -- all three give the same bits.  wscale: as mcg_conv_desc.wscale (u packed
- * pre-scaled by its inverse; 0 = 1). */
-size_t mcg_conv3x3_wino_x3_weight_bytes(int Cin, int Cout);
+ * pre-scaled by its inverse; 0 = 1).  g: output pixels per transform group -- 2 = F(2,3) (the description above), 4 = F(4,3): six positions for
+ * four outputs, 4.5 products per output; u = wino_pack(w, g=4) (24 / 9 of the OHWI tensor); additionally needs W % 4 == 0 and W >= 16; tile 1 = 64
+ * groups x 128 channels, 2 / 3 = 32 x 64.  Its transform constants cost about 1.5 bits against the direct kernel (measured: tests). */
+size_t mcg_conv3x3_wino_x3_weight_bytes(int Cin, int Cout, int g);
 int mcg_conv3x3_wino_x3(mcg_stream s, const float* x, const void* u, const float* bias, float* y, int frames, int H, int W,
-                        int Cin, int Cout, int relu, int tile, float wscale);
+                        int Cin, int Cout, int relu, int tile, float wscale, int g);
 
 /* Stem: conv 7x7 s2 p3 (3->64) + BN + ReLU then max-pool 3x3 s2 p1 (resnet.py:636-639).
  * img is the reference's NCHW f32 frame tensor.  w_stem is the packed stem weight
@@ -219,6 +221,8 @@ typedef struct {
                            mcg_conv3x3_wino_x3 (packing.py::wino_pack; wino_x3.hpp);
                          MCG_F32: ignored */
   float wscale;       /* MCG_F16X3: the power of two w AND wf were pre-scaled by the inverse of (mcg_conv_desc.wscale); 0 = 1 = unscaled */
+  const void* wf4;    /* optional, MCG_F16X3, 3x3 / stride 1 / pad 1 convs: the F(4,3) operand of mcg_conv3x3_wino_x3 (wino_pack(w, g=4), same pre-scale);
+                         used on maps whose width is a multiple of 4 and at least 16, wf (F(2,3)) elsewhere; NULL -> wf only */
 } mcg_conv_weights;
 
 /* A fused bottleneck tail of the MCG_F16X3 engine (bneck_x3.hpp): conv2 (3x3) -> conv3 (1x1, + downsample as a second K source or
@@ -291,7 +295,8 @@ void mcg_engine_destroy(mcg_engine* e);
  *   pointwise_stream  0/1 HBM-bound 1x1 convs (layer2, layer3 conv3, P2 / P3 laterals) by the persistent register-resident-weight
  *                     kernel pw_single.hpp (bf16; default 1)
  *   bottleneck_fused  0/1 the fused bottleneck tails handed over in mcg_model_weights.fused (f16x3; default 1)
- *   winograd          0/1 stride-1 3x3 convs that carry a Winograd copy (mcg_conv_weights.wf) by wino_x3.hpp (f16x3; default 1)
+ *   winograd          0/1/2 stride-1 3x3 convs that carry a Winograd copy by wino_x3.hpp (f16x3): 0 off, 1 (default) F(2,3) (mcg_conv_weights.wf), 2 F(4,3)
+ *                     on maps whose shape allows it (mcg_conv_weights.wf4; 6 % faster there, four times the operator error), F(2,3) elsewhere
  *   range_audit       0/1 DEBUG (MCG_F32 / MCG_F16X3; default 0): after every activation tensor the trunk writes, a counting kernel tallies the
  *                     values beyond the fp16 range (|x| > 65504: an f16x3 operand half would saturate there) and the non-finite ones;
  *                     read and reset with mcg_engine_range_audit.  Turning it on allocates the counters (the library's only allocation,

@@ -36,7 +36,9 @@ struct mcg_engine {
   mcg_conv_weights lateral[4], fpn_out[4], c3_ds[4];
   std::vector<mcg_fused_block> fused;   // f16x3: fused bottleneck tails (bneck_x3.hpp), looked up by conv2 index
   bool bneck_fused = true;
-  bool winograd = true;        // f16x3: stride-1 3x3 convs with a Winograd-packed weight copy (mcg_conv_weights.wf) run wino_x3.hpp
+  int winograd = 1;            // f16x3: stride-1 3x3 convs with a Winograd-packed weight copy run wino_x3.hpp: 0 off, 1 (default) F(2,3) (mcg_conv_weights.wf),
+                               // 2 F(4,3) where the layer's shape allows it and the weights carry that copy (wf4), F(2,3) elsewhere: 6 % faster on
+                               // the 56-wide maps for four times the operator error -- opt-in
   // range audit (debug option, f32-storage engines): per activation tensor the trunk writes, how many values lie beyond the fp16 range
   // (|x| > 65504: an f16x3 operand half would saturate) and how many are not finite.  Counters live on the device; read by mcg_engine_range_audit.
   static constexpr int kAuditCap = 256;
@@ -201,7 +203,7 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "pointwise_pair")) e->pw_pair = value != 0;
   else if (!strcmp(name, "pointwise_stream")) e->pw_single = value != 0;
   else if (!strcmp(name, "bottleneck_fused")) e->bneck_fused = value != 0;
-  else if (!strcmp(name, "winograd")) e->winograd = value != 0;
+  else if (!strcmp(name, "winograd")) { MCG_CHECK_ARG(value >= 0 && value <= 2, "winograd must be 0, 1 or 2"); e->winograd = value; }
   else if (!strcmp(name, "range_audit")) {
     MCG_CHECK_ARG(e->dt != MCG_BF16 || !value, "range_audit: f32-storage engines only (MCG_F32, MCG_F16X3)");
     if (value && !e->audit_dev) {   // set-up, not the hot path: the only allocation the library ever makes
@@ -374,17 +376,20 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
     if (prc) { mcg_set_error("pw_single_x3 launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
   }
-  if (dt == MCG_F16X3 && e->winograd && e->ctx.tile < 0 && cw.wf && cw.k == 3 && cw.stride == 1 && cw.pad == 1 && rm == MCG_RES_NONE &&
-      wino_x3_applicable(n, h, w, cw.cin, cw.cout)) {
+  // F(4,3) where the layer's shape allows it and the weights carry that copy, else F(2,3), else the direct kernel -- by SHAPE only
+  const int wg = (dt == MCG_F16X3 && e->winograd && e->ctx.tile < 0 && cw.k == 3 && cw.stride == 1 && cw.pad == 1 && rm == MCG_RES_NONE)
+                     ? ((cw.wf4 && e->winograd >= 2 && wino_x3_applicable(n, h, w, cw.cin, cw.cout, 4)) ? 4 : ((cw.wf && wino_x3_applicable(n, h, w, cw.cin, cw.cout, 2)) ? 2 : 0))
+                     : 0;
+  if (wg) {
     // f16x3: the 3x3 / stride 1 convs (FPN outputs, layer3's conv2) as a 1-D Winograd F(2,3) contraction (wino_x3.hpp); FLOPs and bytes
     // are booked as the DIRECT convolution's: the roofline keeps counting the reference's arithmetic
     WinoParams wp;
     memset(&wp, 0, sizeof(wp));
-    wp.x = (const float*)x; wp.u = cw.wf; wp.bias = cw.bias; wp.y = (float*)y;
+    wp.x = (const float*)x; wp.u = wg == 4 ? cw.wf4 : cw.wf; wp.bias = cw.bias; wp.y = (float*)y;
     wp.H = h; wp.W = w; wp.frames = n; wp.Cin = cw.cin; wp.Cout = cw.cout; wp.relu = relu; wp.wscale = cw.wscale;
     ProfRec* rec = prof_begin(e->ctx, s, 73, (int)M, cw.cout, 9 * cw.cin, 2.0 * M * 9.0 * cw.cin * cw.cout,
                               4.0 * ((double)M * (cw.cin + cw.cout) + 9.0 * cw.cin * cw.cout));
-    const int wrc = launch_wino_x3(s, wp);
+    const int wrc = launch_wino_x3(s, wp, -1, wg);
     prof_end(rec, s);
     if (wrc) { mcg_set_error("wino_x3 launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
@@ -656,22 +661,22 @@ extern "C" int mcg_bottleneck_x3(mcg_stream s, const float* x, const float* src2
   return MCG_OK;
 }
 
-extern "C" size_t mcg_conv3x3_wino_x3_weight_bytes(int Cin, int Cout) {
-  return (Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % wnx::UNT == 0) ? wino_x3_weight_bytes(Cin, Cout) : 0;
+extern "C" size_t mcg_conv3x3_wino_x3_weight_bytes(int Cin, int Cout, int g) {
+  return (Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % wnx::UNT == 0 && (g == 2 || g == 4)) ? wino_x3_weight_bytes(Cin, Cout, g) : 0;
 }
 extern "C" int mcg_conv3x3_wino_x3(mcg_stream s, const float* x, const void* u, const float* bias, float* y, int frames, int H, int W,
-                                   int Cin, int Cout, int relu, int tile, float wscale) {
+                                   int Cin, int Cout, int relu, int tile, float wscale, int g) {
   MCG_CHECK_ARG(x && u && y, "mcg_conv3x3_wino_x3: null pointer");
   MCG_CHECK_ARG(tile >= 0 && tile <= 3, "mcg_conv3x3_wino_x3: tile must be 0 (by grid size) .. 3");
-  if (!wino_x3_applicable(frames, H, W, Cin, Cout)) {
-    mcg_set_error("mcg_conv3x3_wino_x3: unsupported shape (frames=%d %dx%d, %d -> %d channels): Cin %% 32, Cout %% 128, W <= 62, window <= 48 KiB per 16 channels", frames, H, W, Cin, Cout);
+  if (!wino_x3_applicable(frames, H, W, Cin, Cout, g)) {
+    mcg_set_error("mcg_conv3x3_wino_x3: unsupported shape (frames=%d %dx%d, %d -> %d channels, F(%d,3)): Cin %% 32, Cout %% 128, W <= 62 (F(4,3): W %% 4 == 0, W >= 16), a tile's window within its buffer", frames, H, W, Cin, Cout, g);
     return MCG_ERR_UNSUPPORTED;
   }
   WinoParams wp;
   memset(&wp, 0, sizeof(wp));
   wp.x = x; wp.u = u; wp.bias = bias; wp.y = y; wp.H = H; wp.W = W; wp.frames = frames; wp.Cin = Cin; wp.Cout = Cout; wp.relu = relu;
   wp.wscale = wscale;
-  if (launch_wino_x3((hipStream_t)s, wp, tile - 1)) { mcg_set_error("mcg_conv3x3_wino_x3: launch failed"); return MCG_ERR_HIP; }
+  if (launch_wino_x3((hipStream_t)s, wp, tile - 1, g)) { mcg_set_error("mcg_conv3x3_wino_x3: launch failed"); return MCG_ERR_HIP; }
   return MCG_OK;
 }
 

@@ -37,14 +37,24 @@
 //   * epilogue: the four positions of a pair live in four waves; they meet in LDS (two passes of 64 pairs x 128 channels x 4), the
 //     output transform + bias (+ ReLU) is applied on 16-byte channel chunks and both pixels of a pair are stored.
 // Batch invariance: a pair's arithmetic does not depend on the tile it falls into, so a clip's result is independent of the batch.
+//
+// G = 4 (round 4, second half): the same kernel with F(4,3) -- groups of FOUR output pixels, six positions (points 0, +-1, +-2, inf),
+//     V = B^T d with B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]   (<= 4 terms: 1 mul + 3 fma)
+//     U = G g,  G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//     y = A^T M, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// 4.5 instead of 6 products per output.  Six positions = 12 waves of one row tile (64 groups x 128 channels) or 6 waves (32 x 64); a K step's
+// weights are 48 KiB, which leaves 2 x 32 KiB of window: where a tile that straddles two frames would need more (56-pixel maps), tiles are
+// cut at frame boundaries (tiles_per_frame).  The window's 1 KiB pieces hold two PHASES (pixel index mod G) of eight groups each; for G = 2
+// that is the even / odd layout above.  Accuracy: the transform constants cost ~1.5 bits (emulated 1.9e-6 of scale against 6e-7 for the direct
+// kernel) -- acceptable only because the weights are pre-scaled (without: 1.5e-5); DESIGN.md 3.1h.
 #pragma once
 #include "igemm_dma.hpp"
 
 namespace wnx {
 constexpr int KS = 16;                              // input channels per K step
 constexpr int UNT = 128;                            // output channels per weight block of the packed operand (packing.py::wino_pack)
-constexpr int USTAGE = 4 * 4 * 2 * 1024;            // one K step of one block: [nu 4][channel tile 4][high, low][64 lanes][16 B]
-constexpr int WIN_CAP = 48 * 1024;                  // one window buffer (pieces of 1 KiB; a workgroup may use fewer)
+constexpr int ustage(int g) { return (g + 2) * 4 * 2 * 1024; }   // one K step of one block: [nu G + 2][channel tile 4][high, low][64 lanes][16 B]
+constexpr int wcap(int g, int ct) { return (g == 4 && ct == 4) ? 32 * 1024 : 48 * 1024; }   // one window buffer (1 KiB pieces; a workgroup may use fewer)
 }  // namespace wnx
 
 struct WinoParams {
@@ -52,31 +62,41 @@ struct WinoParams {
   const void* u;         // packing.py::wino_pack: fp16 [Cout / 128][3 Cin / 16 K steps][nu][ct][high, low][lane][8]
   const float* bias;     // [Cout] or NULL
   float* y;              // [frames][H][W][Cout] f32
-  int H, W, PW, frames, Cin, Cout, relu;
-  int total_pairs, n_tiles;
+  int H, W, PW, frames, Cin, Cout, relu;   // PW: groups (of G output pixels) per row
+  int total_pairs, n_tiles;                // groups in all frames; channel tiles
+  int tpf, gpf;                            // tiles per frame (0: tiles run over frame boundaries), groups per frame
   float wscale;          // the transformed sums are multiplied by this power of two before the bias (pre-scaled weights); 0 = 1
 };
 
-// NB: 1 KiB blocks per window row = ceil((2 PW + 2) / 16).  Tile: RH x RT row tiles of 32 pairs, CT column tiles of 32 channels; 4 RH waves.
-template <int NB, int RH, int RT, int CT>
-__global__ __launch_bounds__(256 * RH, 1) void wino_x3_kernel(const WinoParams p) {
+// NB: 1 KiB pieces per window row.  Tile: RH x RT row tiles of 32 groups, CT column tiles of 32 channels; (G + 2) RH waves.
+template <int NB, int RH, int RT, int CT, int G>
+__global__ __launch_bounds__(64 * (G + 2) * RH, 1) void wino_x3_kernel(const WinoParams p) {
   using namespace wnx;
-  constexpr int NW = 4 * RH, NTHREADS = 64 * NW, MT = 32 * RH * RT, NT = 32 * CT;
-  constexpr int ROWB = NB * 1024;
-  constexpr int BSTAGE = 4 * CT * 2 * 1024;           // this workgroup's share of a K step's weights
-  constexpr int BPW = 8 * CT / NW;                    // weight pieces per wave and K step
-  constexpr int MAXP = WIN_CAP / 1024 / NW;           // window pieces per wave and slice (upper bound)
-  static_assert(8 * CT % NW == 0 && UNT % NT == 0, "tile shape");
+  constexpr int NV = G + 2, NW = NV * RH, NTHREADS = 64 * NW, MT = 32 * RH * RT, NT = 32 * CT;
+  constexpr int ROWB = NB * 1024, WIN_CAP = wcap(G, CT), USTAGE = ustage(G);
+  constexpr int BSTAGE = NV * CT * 2 * 1024;          // this workgroup's share of a K step's weights
+  constexpr int BPW = 2 * NV * CT / NW;               // weight pieces per wave and K step
+  constexpr int MAXP = (WIN_CAP / 1024 + NW - 1) / NW;   // window pieces per wave and slice (upper bound)
+  constexpr int NTERM = G == 2 ? 2 : 4;               // input pixels per transformed value
+  static_assert((2 * NV * CT) % NW == 0 && UNT % NT == 0 && (G == 2 || G == 4), "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const s_win = smem;
   char* const s_b = smem + 2 * WIN_CAP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nu = wave & 3, rh = wave >> 2;
+  const int nu = wave % NV, rh = wave / NV;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = logical / p.n_tiles, ntile = logical - mt * p.n_tiles;
-  const int q0 = mt * MT;
-  const int q_last = min(q0 + MT - 1, p.total_pairs - 1);
+  int q0, q_end;
+  if (p.tpf > 0) {                                    // tiles cut at frame boundaries
+    const int f = mt / p.tpf, t = mt - f * p.tpf;
+    q0 = f * p.gpf + t * MT;
+    q_end = min(q0 + MT, (f + 1) * p.gpf);
+  } else {
+    q0 = mt * MT;
+    q_end = min(q0 + MT, p.total_pairs);
+  }
+  const int q_last = q_end - 1;
   const int H1 = p.H + 1;
   // window slot of global output row R = f H + y: R + f + 1 (slot f (H + 1) is the zero row in front of frame f)
   auto slot_of = [&](int q) { const int R = q / p.PW; return R + R / p.H + 1; };
@@ -90,7 +110,7 @@ __global__ __launch_bounds__(256 * RH, 1) void wino_x3_kernel(const WinoParams p
   const uint32_t lds_win = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)s_win;
   const uint32_t lds_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)s_b;
 
-  // ---- this wave's window pieces: piece pi = wave + NW n covers block pi % NB of window row pi / NB (uniform, SGPRs)
+  // ---- this wave's window pieces: piece pi = wave + NW n covers piece pi % NB of window row pi / NB (uniform, SGPRs)
   uint32_t prow[MAXP];
   int pblk[MAXP];
   bool pok[MAXP], prowok[MAXP];
@@ -103,10 +123,13 @@ __global__ __launch_bounds__(256 * RH, 1) void wino_x3_kernel(const WinoParams p
     prow[n] = __builtin_amdgcn_readfirstlane((uint32_t)(((long long)(f * p.H + r - 1) * p.W) * p.Cin * 4));
     pblk[n] = b;
   });
-  // lane l of a piece: parity l >> 5, pixel pair (l >> 2) & 7 of the block, LDS chunk slot l & 3 (holds channel chunk slot ^ swizzle)
-  const int l_par = lane >> 5, l_i = (lane >> 2) & 7, l_cs = lane & 3;
-  auto win_voff = [&](int b) -> uint32_t {
-    const int x = 16 * b + 2 * l_i + l_par - 1;
+  // A window row is a sequence of blocks of 8 G pixels: phase ph = pixel % G, group index i = pixel / G: [ph][i (8)][64 B].  A 1 KiB piece
+  // carries two phases of a block (G = 2: the whole block); lane l: phase 2 (piece % (G / 2)) + (l >> 5), group (l >> 2) & 7 of the block,
+  // LDS chunk slot l & 3 (holds channel chunk slot ^ swizzle).
+  const int l_ph = lane >> 5, l_i = (lane >> 2) & 7, l_cs = lane & 3;
+  auto win_voff = [&](int pc) -> uint32_t {
+    const int b = pc / (G / 2), hph = pc - b * (G / 2);
+    const int x = (8 * b + l_i) * G + 2 * hph + l_ph - 1;
     const int c = l_cs ^ ((2 * b + (l_i >> 2)) & 3);
     return (unsigned)x < (unsigned)p.W ? (uint32_t)((x * p.Cin + 4 * c) * 4) : MCG_OOB_OFFSET;
   };
@@ -130,23 +153,38 @@ __global__ __launch_bounds__(256 * RH, 1) void wino_x3_kernel(const WinoParams p
     });
   };
 
-  // ---- A operand addresses: pair (lane & 31) of row tile RT rh + rt, channels 8 (lane >> 5) .. + 7 of the slice = chunks 2 h, 2 h + 1
+  // ---- input transform of this wave's position: V = sum_t coef[t] * d[off[t]] (pixel offsets inside the group's G + 2 pixel footprint)
+  int toff[NTERM];
+  float tco[NTERM];
+  if constexpr (G == 2) {
+    toff[0] = nu == 0 ? 0 : 1; toff[1] = nu == 3 ? 3 : 2;
+    tco[0] = 1.f; tco[1] = nu == 1 ? 1.f : -1.f;            // V = a + sgn b
+  } else {
+    const int o4[6][4] = {{0, 2, 4, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 3, 5, 5}};
+    const float c4[6][4] = {{4.f, -5.f, 1.f, 0.f}, {-4.f, -4.f, 1.f, 1.f}, {4.f, -4.f, -1.f, 1.f}, {-2.f, -1.f, 2.f, 1.f}, {2.f, -1.f, -2.f, 1.f}, {4.f, -5.f, 1.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      toff[t] = o4[0][t]; tco[t] = c4[0][t];
+#pragma unroll
+      for (int v = 1; v < 6; ++v)
+        if (nu == v) { toff[t] = o4[v][t]; tco[t] = c4[v][t]; }
+    }
+  }
+  // ---- A operand addresses: group (lane & 31) of row tile RT rh + rt, channels 8 (lane >> 5) .. + 7 of the slice = chunks 2 h, 2 h + 1
   const int pl = lane & 31, h = lane >> 5;
-  const int o_a = nu == 0 ? 0 : 1, o_b = nu == 3 ? 3 : 2;
-  const float sgn = nu == 1 ? 1.f : -1.f;            // V = a + sgn b
-  const char* ap[RT][2][2];
+  const char* ap[RT][NTERM][2];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    const int q = min(q0 + (RT * rh + rt) * 32 + pl, p.total_pairs - 1);   // pairs beyond the end repeat the last one; never stored
-    const int R = q / p.PW, xp = q - R * p.PW;
+    const int q = min(q0 + (RT * rh + rt) * 32 + pl, q_last);               // groups beyond the end repeat the last one; never stored
+    const int R = q / p.PW, xg = q - R * p.PW;
     const int jrow = (R + R / p.H + 1) - sig_b - 1;                          // window row of tap ky = 0
 #pragma unroll
-    for (int px = 0; px < 2; ++px) {
-      const int wx = 2 * xp + (px ? o_b : o_a);
-      const int pp = wx >> 1, par = wx & 1, swz = (pp >> 2) & 3;
-      const int off = jrow * ROWB + (pp >> 3) * 1024 + par * 512 + (pp & 7) * 64;
+    for (int t = 0; t < NTERM; ++t) {
+      const int wx = G * xg + toff[t];
+      const int pp = wx / G, ph = wx - pp * G, swz = (pp >> 2) & 3;
+      const int off = jrow * ROWB + (pp >> 3) * (G * 512) + ph * 512 + (pp & 7) * 64;
 #pragma unroll
-      for (int ch = 0; ch < 2; ++ch) ap[rt][px][ch] = s_win + off + (((2 * h + ch) ^ swz) << 4);
+      for (int ch = 0; ch < 2; ++ch) ap[rt][t][ch] = s_win + off + (((2 * h + ch) ^ swz) << 4);
     }
   }
   const char* const bp = s_b + nu * (CT * 2 * 1024) + lane * 16;
@@ -159,93 +197,123 @@ __global__ __launch_bounds__(256 * RH, 1) void wino_x3_kernel(const WinoParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // A fragments of one K step: two LDS reads per pixel, V = a + sgn b, the contraction kernel's in-register split
-  auto prep = [&](auto wbc, auto kyc, bf16x8 (&ah)[RT], bf16x8 (&al)[RT]) {
+  // A fragments of one K step, in two halves: the raw pixel reads (LDS), then the f32 transform + the contraction kernel's in-register split
+  struct Raw { uint4 d[RT][NTERM][2]; };
+  auto load_raw = [&](auto wbc, auto kyc, Raw& r) {
     constexpr int AOFF = decltype(wbc)::value * WIN_CAP + decltype(kyc)::value * ROWB;
 #pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int t = 0; t < NTERM; ++t) { r.d[rt][t][0] = *(const uint4*)(ap[rt][t][0] + AOFF); r.d[rt][t][1] = *(const uint4*)(ap[rt][t][1] + AOFF); }
+  };
+  auto transform = [&](const Raw& r, bf16x8 (&ah)[RT], bf16x8 (&al)[RT]) {
+#pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const uint4 a0 = *(const uint4*)(ap[rt][0][0] + AOFF), a1 = *(const uint4*)(ap[rt][0][1] + AOFF);
-      const uint4 b0 = *(const uint4*)(ap[rt][1][0] + AOFF), b1 = *(const uint4*)(ap[rt][1][1] + AOFF);
-      uint4 v0, v1;
-      v0.x = __float_as_uint(fmaf(sgn, __uint_as_float(b0.x), __uint_as_float(a0.x)));
-      v0.y = __float_as_uint(fmaf(sgn, __uint_as_float(b0.y), __uint_as_float(a0.y)));
-      v0.z = __float_as_uint(fmaf(sgn, __uint_as_float(b0.z), __uint_as_float(a0.z)));
-      v0.w = __float_as_uint(fmaf(sgn, __uint_as_float(b0.w), __uint_as_float(a0.w)));
-      v1.x = __float_as_uint(fmaf(sgn, __uint_as_float(b1.x), __uint_as_float(a1.x)));
-      v1.y = __float_as_uint(fmaf(sgn, __uint_as_float(b1.y), __uint_as_float(a1.y)));
-      v1.z = __float_as_uint(fmaf(sgn, __uint_as_float(b1.z), __uint_as_float(a1.z)));
-      v1.w = __float_as_uint(fmaf(sgn, __uint_as_float(b1.w), __uint_as_float(a1.w)));
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t e0[4] = {r.d[rt][0][c].x, r.d[rt][0][c].y, r.d[rt][0][c].z, r.d[rt][0][c].w};
+        const uint32_t e1[4] = {r.d[rt][1][c].x, r.d[rt][1][c].y, r.d[rt][1][c].z, r.d[rt][1][c].w};
+        if constexpr (G == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * c + e] = fmaf(tco[1], __uint_as_float(e1[e]), __uint_as_float(e0[e]));     // a + sgn b
+        } else {
+          const uint32_t e2[4] = {r.d[rt][2][c].x, r.d[rt][2][c].y, r.d[rt][2][c].z, r.d[rt][2][c].w};
+          const uint32_t e3[4] = {r.d[rt][3][c].x, r.d[rt][3][c].y, r.d[rt][3][c].z, r.d[rt][3][c].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[4 * c + e] = fmaf(tco[3], __uint_as_float(e3[e]), fmaf(tco[2], __uint_as_float(e2[e]), fmaf(tco[1], __uint_as_float(e1[e]), tco[0] * __uint_as_float(e0[e]))));
+        }
+      }
+      const uint4 v0 = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+      const uint4 v1 = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
       split_f32x8(v0, v1, ah[rt], al[rt]);
     }
-  };
-  auto mma = [&](auto slc, const bf16x8 (&ah)[RT], const bf16x8 (&al)[RT]) {
-    constexpr int BOFF = decltype(slc)::value * BSTAGE;
-    bf16x8 bh[CT], bl[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      bh[ct] = __builtin_bit_cast(bf16x8, *(const uint4*)(bp + BOFF + ct * 2048));
-      bl[ct] = __builtin_bit_cast(bf16x8, *(const uint4*)(bp + BOFF + ct * 2048 + 1024));
-    }
-    // small terms first; consecutive MFMAs never share an accumulator (igemm_dma.hpp, X3 mode: the same order)
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-      for (int j = 0; j < CT; ++j) acc[i][j] = x3_mfma(al[i], bh[j], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-      for (int j = 0; j < CT; ++j) acc[i][j] = x3_mfma(ah[i], bl[j], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-      for (int j = 0; j < CT; ++j) acc[i][j] = x3_mfma(ah[i], bh[j], acc[i][j]);
   };
 
   // ---- K loop: step k = 3 cs + ky (slice cs of 16 channels, y tap ky); weights of step k in ring stage k & 1, window slice cs in
   // buffer cs & 1.  Unrolled by six steps (two slices) so that stage, buffer and tap are immediates.  After a barrier every wave
-  // of the workgroup stands at the same instruction, so whatever a step does before its MFMAs idles the matrix pipe of all four
-  // SIMDs at once: the A fragments of step k + 1 are therefore prepared UNDER step k's MFMAs (the window slice of step k + 1 is
-  // resident by then: a slice is issued at its predecessor's first step and waited for -- vmcnt(0) -- at the second).
+  // of the workgroup stands at the same instruction, so whatever a step does BEFORE its MFMAs idles the matrix pipe of all four SIMDs
+  // at once.  A step therefore starts its MFMAs as soon as its weight fragments are read, and everything that serves the NEXT step is
+  // issued behind them: the LDS-DMA pieces of the next weight stage / window slice one at a time behind the first MFMAs (a piece costs
+  // 60 - 180 issue cycles; five to ten of them in front of the MFMAs cost the step a quarter of its time), the next step's A fragments
+  // (raw reads, transform, split) under the rest.  (The window slice of step k + 1 is resident by then: a slice is issued at its
+  // predecessor's first step and waited for -- vmcnt(0) -- at the second.)
   issue_window(0, lds_win);
   issue_b(0, lds_b);
   bf16x8 fh[2][RT], fl[2][RT];                            // [step parity][row tile]
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  prep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fh[0], fl[0]);
-  constexpr int NM = 3 * RT * CT, VPM = (32 * RT + NM - 4) / (NM - 3);   // MFMAs per step; VALU issued behind each of the first NM - 3
+  {
+    Raw r0;
+    load_raw(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, r0);
+    transform(r0, fh[0], fl[0]);
+  }
+  constexpr int NM1 = RT * CT;                            // MFMAs of one term
+  constexpr int PVALU = (G == 2 ? 32 : 56) * RT, VPM = (PVALU + 2 * NM1 - 1) / (2 * NM1);   // transform + split VALU behind each MFMA of the last two terms
 #pragma nounroll
   for (int s2 = 0; s2 < NSL / 2; ++s2) {
     static_for<6>([&](auto uc) {
       constexpr int U = decltype(uc)::value, KY = U % 3, SL = U & 1, WB = U / 3;
       constexpr int U1 = (U + 1) % 6, KY1 = U1 % 3, WB1 = U1 / 3;
+      constexpr int BOFF = SL * BSTAGE;
       const int k = 6 * s2 + U, cs = 2 * s2 + WB;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces landed; its reads of the previous step are done
       __builtin_amdgcn_s_barrier();                                  // ... and everyone's
-      issue_b(min(k + 1, KT - 1), lds_b + (SL ^ 1) * BSTAGE);       // (the last step re-fetches its own stage: no branch in the step body)
+      bf16x8 bh[CT], bl[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        bh[ct] = __builtin_bit_cast(bf16x8, *(const uint4*)(bp + BOFF + ct * 2048));
+        bl[ct] = __builtin_bit_cast(bf16x8, *(const uint4*)(bp + BOFF + ct * 2048 + 1024));
+      }
+      Raw raw;
+      load_raw(std::integral_constant<int, WB1>{}, std::integral_constant<int, KY1>{}, raw);   // (the last step reads pixels nobody uses: valid addresses, no branch)
+      __builtin_amdgcn_sched_barrier(0);
+      // term 1 (activation low x weight high; small terms first, consecutive MFMAs never share an accumulator: igemm_dma.hpp's order), one
+      // DMA piece of the next weight stage behind each of its first MFMAs, then the next window slice's pieces
+      const uint32_t kn = (uint32_t)min(k + 1, KT - 1) * USTAGE, bdst = lds_b + (SL ^ 1) * BSTAGE + (uint32_t)wave * (BPW * 1024u);
+      static_for<NM1>([&](auto mc) {
+        constexpr int M = decltype(mc)::value, I = M / CT, J = M % CT;
+        acc[I][J] = x3_mfma(fl[SL][I], bh[J], acc[I][J]);
+        if constexpr (M < BPW) {                                      // (the last step re-fetches its own stage rather than branch)
+          const int pc = wave * BPW + M, pnu = pc / (2 * CT), rest = pc - pnu * (2 * CT);
+          lds_dma16<M * 1024>(b_voff, srd_u, kn + (uint32_t)pnu * 8192u + (uint32_t)rest * 1024u, bdst);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (NM1 < BPW) {
+        static_for<BPW - NM1>([&](auto mc) {
+          constexpr int M = NM1 + decltype(mc)::value;
+          const int pc = wave * BPW + M, pnu = pc / (2 * CT), rest = pc - pnu * (2 * CT);
+          lds_dma16<M * 1024>(b_voff, srd_u, kn + (uint32_t)pnu * 8192u + (uint32_t)rest * 1024u, bdst);
+        });
+      }
       if (KY == 0 && cs + 1 < NSL) issue_window(cs + 1, lds_win + (WB ^ 1) * WIN_CAP);
-      // one basic block from here to the next barrier: this step's MFMAs with the next step's A preparation (4 RT LDS reads, 32 RT VALU)
-      // issued between them -- the last step prepares fragments nobody uses (valid addresses) rather than branch
-      prep(std::integral_constant<int, WB1>{}, std::integral_constant<int, KY1>{}, fh[SL ^ 1], fl[SL ^ 1]);
-      mma(std::integral_constant<int, SL>{}, fh[SL], fl[SL]);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * CT + 4 * RT, 0);   // the B fragments of this step, then the raw A pixels of the next
-      static_for<NM - 3>([&](auto) {
+      // terms 2 and 3 in one basic block with the next step's transform + split
+      transform(raw, fh[SL ^ 1], fl[SL ^ 1]);
+#pragma unroll
+      for (int i2 = 0; i2 < RT; ++i2)
+#pragma unroll
+        for (int j2 = 0; j2 < CT; ++j2) acc[i2][j2] = x3_mfma(fh[SL][i2], bl[j2], acc[i2][j2]);
+#pragma unroll
+      for (int i2 = 0; i2 < RT; ++i2)
+#pragma unroll
+        for (int j2 = 0; j2 < CT; ++j2) acc[i2][j2] = x3_mfma(fh[SL][i2], bh[j2], acc[i2][j2]);
+      static_for<2 * NM1 - 1>([&](auto) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
       });
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
     });
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---- epilogue: output transform across the four positions through LDS, one pass per wave row group (RT x 32 pairs)
-  constexpr int PP = 32 * RT, CPR = NT / 4;                // pairs per pass, 16-byte chunks per row
-  static_assert(4 * PP * NT * 4 <= 2 * WIN_CAP + 2 * BSTAGE && NTHREADS % CPR == 0 && (PP * CPR) % NTHREADS == 0, "epilogue staging");
-  float* const C = (float*)smem;                           // [nu][PP pairs][NT]
-  const int ch4 = (tid % CPR) * 4;
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) bv = *(const float4*)(p.bias + n0 + ch4);
+  // ---- epilogue: output transform across the positions through LDS, one pass per wave row group (RT x 32 groups)
+  constexpr int PP = 32 * RT, CPR = NT / 4;                // groups per pass, 16-byte chunks per row
+  static_assert(NV * PP * NT * 4 <= 2 * WIN_CAP + 2 * BSTAGE, "epilogue staging");
+  float* const C = (float*)smem;                           // [nu][PP groups][NT]
   const float wsc = p.wscale > 0.f ? p.wscale : 1.f;
 #pragma unroll 1
   for (int pass = 0; pass < RH; ++pass) {
@@ -259,84 +327,121 @@ __global__ __launch_bounds__(256 * RH, 1) void wino_x3_kernel(const WinoParams p
             C[(nu * PP + rt * 32 + mfma32_row(r, lane)) * NT + ct * 32 + (lane & 31)] = acc[rt][ct][r];
     }
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < PP * CPR / NTHREADS; ++it) {
-      const int prl = tid / CPR + it * (NTHREADS / CPR);
+    for (int item = tid; item < PP * CPR; item += NTHREADS) {
+      const int prl = item / CPR, ch4 = (item - prl * CPR) * 4;
       const int q = q0 + pass * PP + prl;
-      if (q < p.total_pairs) {
-        const float4 m0 = *(const float4*)(C + (0 * PP + prl) * NT + ch4), m1 = *(const float4*)(C + (1 * PP + prl) * NT + ch4);
-        const float4 m2 = *(const float4*)(C + (2 * PP + prl) * NT + ch4), m3 = *(const float4*)(C + (3 * PP + prl) * NT + ch4);
-        float4 y0 = make_float4(((m0.x + m1.x) + m2.x) * wsc + bv.x, ((m0.y + m1.y) + m2.y) * wsc + bv.y, ((m0.z + m1.z) + m2.z) * wsc + bv.z, ((m0.w + m1.w) + m2.w) * wsc + bv.w);
-        float4 y1 = make_float4(((m1.x - m2.x) - m3.x) * wsc + bv.x, ((m1.y - m2.y) - m3.y) * wsc + bv.y, ((m1.z - m2.z) - m3.z) * wsc + bv.z, ((m1.w - m2.w) - m3.w) * wsc + bv.w);
-        if (p.relu) {
-          y0.x = fmaxf(y0.x, 0.f); y0.y = fmaxf(y0.y, 0.f); y0.z = fmaxf(y0.z, 0.f); y0.w = fmaxf(y0.w, 0.f);
-          y1.x = fmaxf(y1.x, 0.f); y1.y = fmaxf(y1.y, 0.f); y1.z = fmaxf(y1.z, 0.f); y1.w = fmaxf(y1.w, 0.f);
+      if (q >= q_end) continue;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bv = *(const float4*)(p.bias + n0 + ch4);
+      float4 m[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) m[v] = *(const float4*)(C + (v * PP + prl) * NT + ch4);
+      float4 y[G];
+      if constexpr (G == 2) {
+        y[0] = make_float4(((m[0].x + m[1].x) + m[2].x) * wsc + bv.x, ((m[0].y + m[1].y) + m[2].y) * wsc + bv.y, ((m[0].z + m[1].z) + m[2].z) * wsc + bv.z, ((m[0].w + m[1].w) + m[2].w) * wsc + bv.w);
+        y[1] = make_float4(((m[1].x - m[2].x) - m[3].x) * wsc + bv.x, ((m[1].y - m[2].y) - m[3].y) * wsc + bv.y, ((m[1].z - m[2].z) - m[3].z) * wsc + bv.z, ((m[1].w - m[2].w) - m[3].w) * wsc + bv.w);
+      } else {
+        // y0 = m0 + (m1 + m2) + (m3 + m4); y1 = (m1 - m2) + 2 (m3 - m4); y2 = (m1 + m2) + 4 (m3 + m4); y3 = (m1 - m2) + 8 (m3 - m4) + m5
+#define MCG_W4(F)                                                                                                            \
+        {                                                                                                                    \
+          const float s12 = m[1].F + m[2].F, d12 = m[1].F - m[2].F, s34 = m[3].F + m[4].F, d34 = m[3].F - m[4].F;            \
+          y[0].F = ((m[0].F + s12) + s34) * wsc + bv.F;                                                                      \
+          y[1].F = fmaf(2.f, d34, d12) * wsc + bv.F;                                                                         \
+          y[2].F = fmaf(4.f, s34, s12) * wsc + bv.F;                                                                         \
+          y[3].F = (fmaf(8.f, d34, d12) + m[5].F) * wsc + bv.F;                                                              \
         }
-        const int R = q / p.PW, xo = 2 * (q - R * p.PW);
-        float* yp = p.y + ((long long)R * p.W + xo) * p.Cout + n0 + ch4;
-        *(float4*)yp = y0;
-        if (xo + 1 < p.W) *(float4*)(yp + p.Cout) = y1;
+        MCG_W4(x) MCG_W4(y) MCG_W4(z) MCG_W4(w)
+#undef MCG_W4
+      }
+      const int R = q / p.PW, xo = G * (q - R * p.PW);
+      float* yp = p.y + ((long long)R * p.W + xo) * p.Cout + n0 + ch4;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        if (xo + j >= p.W) break;
+        float4 o = y[j];
+        if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *(float4*)(yp + (long long)j * p.Cout) = o;
       }
     }
     __syncthreads();
   }
 }
 
-// Tile shapes: 0 = 128 pairs x 128 channels (8 waves), 1 = 64 x 64 (8 waves), 2 = 32 x 64 (4 waves)
-static inline int wino_x3_tile_pairs(int shape) { return shape == 0 ? 128 : (shape == 1 ? 64 : 32); }
+// Tile shapes.  G = 2: 0 = 128 pairs x 128 channels (8 waves), 1 = 64 x 64 (8 waves), 2 = 32 x 64 (4 waves).  G = 4: 0 = 64 groups x 128
+// channels (12 waves), 1 or 2 = 32 x 64 (6 waves).
+static inline int wino_x3_tile_groups(int g, int shape) { return g == 2 ? (shape == 0 ? 128 : (shape == 1 ? 64 : 32)) : (shape == 0 ? 64 : 32); }
 static inline int wino_x3_tile_channels(int shape) { return shape == 0 ? 128 : 64; }
-// blocks per window row and the largest window (rows) a tile of mt pairs can need: its rows, the zero rows between frames, two halo rows
-static inline int wino_x3_blocks(int W) { return (2 * ((W + 1) / 2) + 2 + 15) / 16; }
-static inline int wino_x3_max_rows(int H, int W, int mt) {
-  const int PW = (W + 1) / 2;
-  const int rows = (PW - 1 + mt - 1) / PW + 1;
-  const int cross = rows >= 2 ? (rows - 2) / H + 1 : 0;
-  return rows + cross + 2;
+// 1 KiB pieces per window row, and the largest window (rows) a tile of mt groups can need: its rows, the zero rows between frames (cross:
+// tiles run over frame boundaries), two halo rows
+static inline int wino_x3_pieces(int W, int g) { return (g * ((W + g - 1) / g) + 2 + 8 * g - 1) / (8 * g) * (g / 2); }
+static inline int wino_x3_max_rows(int H, int W, int mt, int g, bool cross) {
+  const int PW = (W + g - 1) / g;
+  int rows = (PW - 1 + mt - 1) / PW + 1;
+  if (!cross && rows > H) rows = H;
+  const int nz = cross ? (rows >= 2 ? (rows - 2) / H + 1 : 0) : 0;
+  return rows + nz + 2;
 }
+static inline int wino_x3_nb_template(int pieces) { return pieces <= 1 ? 1 : (pieces <= 2 ? 2 : 4); }
 // 3x3 / stride 1 / pad 1, f16x3: channel counts the tiles divide, a window that fits its buffer, operands inside the 2 GiB descriptor.
 // Decided by the LAYER's shape only (never by the batch): a layer either runs this arithmetic or the direct kernel's for every batch size.
-static inline bool wino_x3_applicable(int frames, int H, int W, int Cin, int Cout) {
-  if (Cin % 32 != 0 || Cout % wnx::UNT != 0 || H < 1 || W < 2 || frames < 1) return false;
-  int nb = wino_x3_blocks(W);
-  if (nb == 3) nb = 4;
-  if (nb > 4) return false;
-  if (wino_x3_max_rows(H, W, 128) * nb * 1024 > wnx::WIN_CAP) return false;
+// -> 0 not applicable, 1 tiles may run over frame boundaries, 2 tiles must be cut at frame boundaries (the window buffer holds no zero row)
+static inline int wino_x3_mode(int frames, int H, int W, int Cin, int Cout, int g) {
+  if (Cin % 32 != 0 || Cout % wnx::UNT != 0 || H < 1 || W < 2 || frames < 1 || (g != 2 && g != 4)) return 0;
+  if (g == 4 && (W % 4 != 0 || W < 16)) return 0;       // F(4,3) only where a row is whole groups and wide enough to pay
+  const int pcs = wino_x3_pieces(W, g);
+  if (pcs > 4) return 0;
+  const int nb = wino_x3_nb_template(pcs);
   const long long px = (long long)frames * H * W;
-  return px * Cin * 4 < MCG_DMA_MAX_BYTES && px * Cout * 4 < MCG_DMA_MAX_BYTES && px < 0x7fffffffLL;
+  if (!(px * Cin * 4 < MCG_DMA_MAX_BYTES && px * Cout * 4 < MCG_DMA_MAX_BYTES && px < 0x7fffffffLL)) return 0;
+  const int mt = wino_x3_tile_groups(g, 0), cap = wnx::wcap(g, 4);
+  if (wino_x3_max_rows(H, W, mt, g, true) * nb * 1024 <= cap) return 1;
+  if (wino_x3_max_rows(H, W, mt, g, false) * nb * 1024 <= cap) return 2;
+  return 0;
 }
-static inline size_t wino_x3_weight_bytes(int Cin, int Cout) { return (size_t)(Cout / wnx::UNT) * (3 * Cin / wnx::KS) * wnx::USTAGE; }
+static inline bool wino_x3_applicable(int frames, int H, int W, int Cin, int Cout, int g = 2) { return wino_x3_mode(frames, H, W, Cin, Cout, g) != 0; }
+static inline size_t wino_x3_weight_bytes(int Cin, int Cout, int g = 2) { return (size_t)(Cout / wnx::UNT) * (3 * Cin / wnx::KS) * wnx::ustage(g); }
 
-template <int NB, int RH, int RT, int CT>
+template <int NB, int RH, int RT, int CT, int G>
 static inline int launch_wino_x3_t(hipStream_t s, const WinoParams& p, int grid) {
-  constexpr int kLds = 2 * wnx::WIN_CAP + 2 * (4 * CT * 2 * 1024);
+  constexpr int kLds = 2 * wnx::wcap(G, CT) + 2 * ((G + 2) * CT * 2 * 1024);
   static bool raised[MCG_MAX_DEVICES] = {false};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
   if (!raised[dev]) {
-    if (hipFuncSetAttribute((const void*)wino_x3_kernel<NB, RH, RT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)wino_x3_kernel<NB, RH, RT, CT, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return 1;
     raised[dev] = true;
   }
-  hipLaunchKernelGGL((wino_x3_kernel<NB, RH, RT, CT>), dim3(grid), dim3(256 * RH), kLds, s, p);
+  hipLaunchKernelGGL((wino_x3_kernel<NB, RH, RT, CT, G>), dim3(grid), dim3(64 * (G + 2) * RH), kLds, s, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 template <int NB>
-static inline int launch_wino_x3_nb(hipStream_t s, const WinoParams& p, int shape, int grid) {
-  if (shape == 0) return launch_wino_x3_t<NB, 2, 2, 4>(s, p, grid);
-  if (shape == 1) return launch_wino_x3_t<NB, 2, 1, 2>(s, p, grid);
-  return launch_wino_x3_t<NB, 1, 1, 2>(s, p, grid);
+static inline int launch_wino_x3_nb(hipStream_t s, const WinoParams& p, int g, int shape, int grid) {
+  if (g == 4) return shape == 0 ? launch_wino_x3_t<NB, 2, 1, 4, 4>(s, p, grid) : launch_wino_x3_t<NB, 1, 1, 2, 4>(s, p, grid);
+  if (shape == 0) return launch_wino_x3_t<NB, 2, 2, 4, 2>(s, p, grid);
+  if (shape == 1) return launch_wino_x3_t<NB, 2, 1, 2, 2>(s, p, grid);
+  return launch_wino_x3_t<NB, 1, 1, 2, 2>(s, p, grid);
 }
-// returns 0 on success; the caller has checked wino_x3_applicable.  shape: -1 = by grid size (the largest tile that still makes ~half
+// returns 0 on success; the caller has checked wino_x3_applicable(.., g).  shape: -1 = by grid size (the largest tile that still makes ~half
 // a chip's worth of workgroups), else forced (tests)
 static const int kWinoMinGrid = 130;
-static inline int launch_wino_x3(hipStream_t s, WinoParams p, int shape = -1) {
-  p.PW = (p.W + 1) / 2;
-  p.total_pairs = p.frames * p.H * p.PW;
-  auto grid_of = [&](int sh) { return ((p.total_pairs + wino_x3_tile_pairs(sh) - 1) / wino_x3_tile_pairs(sh)) * (p.Cout / wino_x3_tile_channels(sh)); };
-  if (shape < 0) shape = grid_of(0) >= kWinoMinGrid ? 0 : (grid_of(1) >= kWinoMinGrid ? 1 : 2);
+static inline int launch_wino_x3(hipStream_t s, WinoParams p, int shape = -1, int g = 2) {
+  const int mode = wino_x3_mode(p.frames, p.H, p.W, p.Cin, p.Cout, g);
+  if (mode == 0) return 1;
+  p.PW = (p.W + g - 1) / g;
+  p.gpf = p.H * p.PW;
+  p.total_pairs = p.frames * p.gpf;
+  auto mtiles = [&](int sh) {
+    const int mt = wino_x3_tile_groups(g, sh);
+    return mode == 2 ? p.frames * ((p.gpf + mt - 1) / mt) : (p.total_pairs + mt - 1) / mt;
+  };
+  auto grid_of = [&](int sh) { return mtiles(sh) * (p.Cout / wino_x3_tile_channels(sh)); };
+  if (shape < 0) shape = grid_of(0) >= kWinoMinGrid ? 0 : ((g == 2 && grid_of(1) >= kWinoMinGrid) ? 1 : 2);
+  if (g == 4 && shape == 1) shape = 2;
   p.n_tiles = p.Cout / wino_x3_tile_channels(shape);
+  p.tpf = mode == 2 ? (p.gpf + wino_x3_tile_groups(g, shape) - 1) / wino_x3_tile_groups(g, shape) : 0;
   const int grid = grid_of(shape);
-  const int nb = wino_x3_blocks(p.W);
-  if (nb == 1) return launch_wino_x3_nb<1>(s, p, shape, grid);
-  if (nb == 2) return launch_wino_x3_nb<2>(s, p, shape, grid);
-  return launch_wino_x3_nb<4>(s, p, shape, grid);
+  const int nb = wino_x3_nb_template(wino_x3_pieces(p.W, g));
+  if (nb == 1) return launch_wino_x3_nb<1>(s, p, g, shape, grid);
+  if (nb == 2) return launch_wino_x3_nb<2>(s, p, g, shape, grid);
+  return launch_wino_x3_nb<4>(s, p, g, shape, grid);
 }

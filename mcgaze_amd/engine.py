@@ -91,19 +91,20 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual
     return y
 
 
-def conv3x3_wino(x, w, bias=None, relu=False, tile=0):
+def conv3x3_wino(x, w, bias=None, relu=False, tile=0, g=2):
     """3x3 / stride 1 / pad 1 conv by the 1-D Winograd F(2,3) kernel of the MCG_F16X3 engine (mcg_conv3x3_wino_x3, wino_x3.hpp):
-    x NHWC f32, w OHWI f32 [Cout,3,3,Cin] (packed here by packing.wino_pack), bias f32 -> NHWC f32.  tile: 0 = by grid size, 1..3 forced."""
+    x NHWC f32, w OHWI f32 [Cout,3,3,Cin] (packed here by packing.wino_pack), bias f32 -> NHWC f32.  tile: 0 = by grid size, 1..3 forced.
+    g = 4: the F(4,3) form of the same kernel (maps whose width is a multiple of 4, at least 16)."""
     _require_gpu()
     lib = L.load()
     from .packing import pow2_prescale, wino_pack
     N, H, W, Cin = x.shape
     Cout = w.shape[0]
     ws, wscale = pow2_prescale(w.cpu())
-    u = wino_pack(ws).to(x.device)
-    assert u.numel() * 2 == lib.mcg_conv3x3_wino_x3_weight_bytes(Cin, Cout), (u.numel(), Cin, Cout)
+    u = wino_pack(ws, g=g).to(x.device)
+    assert u.numel() * 2 == lib.mcg_conv3x3_wino_x3_weight_bytes(Cin, Cout, g), (u.numel(), Cin, Cout)
     y = torch.empty(N, H, W, Cout, dtype=torch.float32, device=x.device)
-    L.check(lib.mcg_conv3x3_wino_x3(_stream(), _ptr(x.contiguous()), _ptr(u), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, int(relu), tile, wscale), 'mcg_conv3x3_wino_x3')
+    L.check(lib.mcg_conv3x3_wino_x3(_stream(), _ptr(x.contiguous()), _ptr(u), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, int(relu), tile, wscale, g), 'mcg_conv3x3_wino_x3')
     return y
 
 
@@ -200,7 +201,8 @@ class HipEngine:
                                      fuse_downsample=fuse_downsample, split=self.code == L.MCG_F16X3)
         w = self.weights
         mk = lambda c: L.ConvWeights(c['w'].data_ptr(), c['bias'].data_ptr(), c['cin'], c['cout'], c['k'], c['stride'], c['pad'],
-                                     c['wf'].data_ptr() if c.get('wf') is not None else None, float(c.get('wscale', 0.0)))
+                                     c['wf'].data_ptr() if c.get('wf') is not None else None, float(c.get('wscale', 0.0)),
+                                     c['wf4'].data_ptr() if c.get('wf4') is not None else None)
         self._convs = (L.ConvWeights * len(w.convs))(*[mk(c) for c in w.convs])
         self._stage_tab = (C.c_void_p * (num_stages * L.SW_COUNT))(*[st[k].data_ptr() for st in w.stages for k in L.STAGE_KEYS])
         self._gaze_tab = _table(w.gaze, L.GAZE_KEYS)

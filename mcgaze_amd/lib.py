@@ -44,7 +44,7 @@ class ConvDesc(C.Structure):
 
 class ConvWeights(C.Structure):
     _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('k', C.c_int),
-                ('stride', C.c_int), ('pad', C.c_int), ('wf', C.c_void_p), ('wscale', C.c_float)]
+                ('stride', C.c_int), ('pad', C.c_int), ('wf', C.c_void_p), ('wscale', C.c_float), ('wf4', C.c_void_p)]
 
 
 class FusedBlock(C.Structure):
@@ -117,10 +117,10 @@ def load():
     lib.mcg_bench_backbone_forward.argtypes = [vp, vp, vp, i, i, i, vp, sz]
     lib.mcg_bench_backbone_levels.argtypes = [vp, vp, i, i, i, C.POINTER(vp)]
     lib.mcg_bottleneck_x3.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
-    lib.mcg_conv3x3_wino_x3.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, C.c_float]
+    lib.mcg_conv3x3_wino_x3.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, C.c_float, i]
     lib.mcg_conv3x3_wino_x3_weight_bytes.restype = sz
     lib.mcg_engine_range_audit.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_char_p), i, C.POINTER(i)]
-    lib.mcg_conv3x3_wino_x3_weight_bytes.argtypes = [i, i]
+    lib.mcg_conv3x3_wino_x3_weight_bytes.argtypes = [i, i, i]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ('mcg_abi_version',):

@@ -102,7 +102,11 @@ def split_pack(w):
     return v.reshape(*lead, 2 * K).contiguous()
 
 
-def wino_pack(w):
+WINO_G = {2: [[1, 0, 0], [0.5, 0.5, 0.5], [-0.5, 0.5, -0.5], [0, 0, 1]],                      # F(2,3); row 2 carries the kernel's sign flip
+          4: [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]}   # F(4,3), points 0, +-1, +-2, inf
+
+
+def wino_pack(w, g=2):
     """f32 / f64 OHWI [Cout][3][3][Cin] (BN folded) -> the weight operand of wino_x3.hpp (mcg_conv3x3_wino_x3; mcg_conv_weights.wf of
     a 3x3 conv, MCG_F16X3): the kernel row (kx) of every y tap transformed by the F(2,3) matrix G = [[1,0,0],[1/2,1/2,1/2],[-1/2,1/2,-1/2],
     [0,0,1]] IN FLOAT64 (row 2 carries the sign flip the kernel's input transform uses), split into fp16 high / low parts
@@ -110,13 +114,14 @@ def wino_pack(w):
     with element (nt, 3 cs + ky, nu, ct, hl, lane, e) = part hl of U_nu[128 nt + 32 ct + (lane & 31)][ky][16 cs + 8 (lane >> 5) + e]:
     one K step's 32 KiB are contiguous and MFMA-fragment-major."""
     cout, kh, kw, cin = w.shape
-    assert (kh, kw) == (3, 3) and cout % 128 == 0 and cin % 32 == 0, tuple(w.shape)
-    g = w.double()
-    u = torch.stack([g[:, :, 0], (g[:, :, 0] + g[:, :, 1] + g[:, :, 2]) / 2, -(g[:, :, 0] - g[:, :, 1] + g[:, :, 2]) / 2, g[:, :, 2]])   # [nu][co][ky][ci]
+    assert (kh, kw) == (3, 3) and cout % 128 == 0 and cin % 32 == 0 and g in WINO_G, (tuple(w.shape), g)
+    gm = torch.tensor(WINO_G[g], dtype=torch.float64, device=w.device)                          # g = 4: F(4,3), six positions [Cout/128][K step][6][4][hl][lane][8]
+    nv = gm.shape[0]
+    u = torch.einsum('pk,oykc->poyc', gm, w.double())                          # [nu][co][ky][ci]
     hi = u.clamp(-65504.0, 65504.0).to(torch.float16)
     lo = (u - hi.double()).clamp(-65504.0, 65504.0).to(torch.float16)
     v = torch.stack([hi, lo])                                                  # [hl][nu][co][ky][ci]
-    v = v.reshape(2, 4, cout // 128, 4, 32, 3, cin // 16, 2, 8)                # hl, nu, nt, ct, n, ky, cs, half, e
+    v = v.reshape(2, nv, cout // 128, 4, 32, 3, cin // 16, 2, 8)               # hl, nu, nt, ct, n, ky, cs, half, e
     v = v.permute(2, 6, 5, 1, 3, 0, 7, 4, 8)                                   # nt, cs, ky, nu, ct, hl, half, n, e
     return v.contiguous().reshape(-1)
 
@@ -194,13 +199,14 @@ class PackedWeights:
 
         # one mcg_conv_weights entry from the folded OIHW weight (or an OHWI one): w, the optional second copy wf and, f16x3 trunk convs,
         # the power-of-two pre-scale both copies carry (pow2_prescale) with its descale factor
-        def entry(w, b, k, stride, pad, wf=None, w_ohwi=None):
+        def entry(w, b, k, stride, pad, wf=None, w_ohwi=None, wf4=None):
             wo = ohwi(w) if w_ohwi is None else w_ohwi
             ws = 0.0
             if split:
                 wo, ws = pow2_prescale(wo)
             return dict(w=cmat(wo), bias=vec(b), cin=wo.shape[3], cout=wo.shape[0], k=k, stride=stride, pad=pad,
-                        wf=wf(wo.permute(0, 3, 1, 2)) if wf is not None else None, wscale=ws)
+                        wf=wf(wo.permute(0, 3, 1, 2)) if wf is not None else None, wscale=ws,
+                        wf4=wf4(wo.permute(0, 3, 1, 2)) if wf4 is not None else None)
         vec = lambda t: self._dev(t.float())
         # fragment-major copies of the 1x1 convs (bf16 engine): operands of the register-resident-weight kernels (pw_pair.hpp, pw_single.hpp)
         if dtype == torch.bfloat16:
@@ -213,6 +219,8 @@ class PackedWeights:
         # f16x3: Winograd F(2,3) copies of the stride-1 3x3 convs whose channel counts wino_x3.hpp tiles (FPN outputs, layer3 / layer4 conv2)
         wf3x3 = (lambda w: self._dev(wino_pack(ohwi(w)))) if split else (lambda w: None)
         wf3x3 = (lambda f: (lambda w: f(w) if (w.shape[0] % 128 == 0 and w.shape[1] % 32 == 0 and w.shape[1] >= 256) else None))(wf3x3)
+        # ... and F(4,3) copies for the FPN output convs (maps whose width is a multiple of 4 and >= 16: P2 / P3 of a 224 x 224 input)
+        wf3x3_g4 = (lambda w: self._dev(wino_pack(ohwi(w), g=4))) if split else None
         w, b = fold_bn(sd, 'backbone.conv1.weight', 'backbone.bn1')
         stem = torch.zeros(64, 7, 8, 4)
         stem[:, :, :7, :3] = w.permute(0, 2, 3, 1)
@@ -267,7 +275,7 @@ class PackedWeights:
             w = sd[f'neck.lateral_convs.{i}.conv.weight']
             self.lateral.append(entry(w, sd[f'neck.lateral_convs.{i}.conv.bias'], 1, 1, 0, wf=wf1x1))
             w = sd[f'neck.fpn_convs.{i}.conv.weight']
-            self.fpn_out.append(entry(w, sd[f'neck.fpn_convs.{i}.conv.bias'], 3, 1, 1, wf=wf3x3))
+            self.fpn_out.append(entry(w, sd[f'neck.fpn_convs.{i}.conv.bias'], 3, 1, 1, wf=wf3x3, wf4=wf3x3_g4))
         self.init_boxes = vec(sd['rpn_head.init_proposal_bboxes.weight'])
         self.init_feats = self._dev(sd['rpn_head.init_proposal_features.weight'].to(dtype))   # read by a non-GEMM kernel: storage dtype
         perm = dyn_permutation()

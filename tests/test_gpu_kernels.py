@@ -160,6 +160,52 @@ def test_conv3x3_wino_x3(eng, case):
     assert err < 4 * err_d + 2e-7, (err, err_d)
 
 
+WINO4_CASES = [
+    # N, H, W, Cin, Cout, relu, bias   F(4,3): width a multiple of 4, at least 16
+    (2, 28, 28, 64, 128, False, True),      # P3's geometry: tiles run over frame boundaries
+    (3, 56, 56, 32, 128, True, True),       # P2's geometry: tiles are cut at frame boundaries (a 32 KiB window holds no zero row)
+    (3, 16, 20, 96, 256, False, True),      # ragged
+    (1, 28, 28, 256, 256, True, False),     # the FPN's channel counts
+    (7, 9, 16, 32, 128, False, True),       # many small frames in one tile
+]
+X3_WINO4_TOL = 3e-6   # of scale; measured <= ~1.5e-6: the F(4,3) constants (x4, x5 in, x8 out) cost about 1.5 bits against the direct kernel
+
+
+@pytest.mark.parametrize('case', WINO4_CASES)
+def test_conv3x3_wino_x3_f43(eng, case):
+    """The F(4,3) form of wino_x3.hpp against the f64 convolution, with the direct kernel's and the F(2,3) kernel's errors beside it."""
+    N, H, W, Cin, Cout, relu, has_b = case
+    g = torch.Generator().manual_seed(4400 + WINO4_CASES.index(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) if has_b else None
+    ref = F.conv2d(x.double(), w.double(), b.double() if has_b else None, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to('cuda:0')
+    bd = b.to('cuda:0') if has_b else None
+    y4 = eng.conv3x3_wino(nhwc(x), nhwc(w), bd, relu=relu, g=4)
+    y2 = eng.conv3x3_wino(nhwc(x), nhwc(w), bd, relu=relu, g=2)
+    yd = eng.conv2d(nhwc(x), nhwc(w), bd, pad=1, relu=relu, split=True)
+    torch.cuda.synchronize()
+    e4, e2, ed = (scale_err(t.permute(0, 3, 1, 2), ref.float()) for t in (y4, y2, yd))
+    print(f'F(4,3) {case}: {e4:.2e} of scale (F(2,3) {e2:.2e}, direct {ed:.2e})')
+    assert e4 < X3_WINO4_TOL, e4
+    for t in (1, 2):   # both tile shapes: the same bits
+        assert torch.equal(y4, eng.conv3x3_wino(nhwc(x), nhwc(w), bd, relu=relu, g=4, tile=t))
+
+
+def test_conv3x3_wino_x3_f43_is_batch_invariant(eng):
+    g = torch.Generator().manual_seed(4500)
+    x = torch.randn(5, 56, 56, 64, generator=g).to('cuda:0')
+    w = (torch.randn(128, 3, 3, 64, generator=g) / 24).to('cuda:0')
+    b = torch.randn(128, generator=g).to('cuda:0')
+    y5 = eng.conv3x3_wino(x, w, b, relu=True, g=4)
+    y2 = eng.conv3x3_wino(x[1:3].contiguous(), w, b, relu=True, g=4)
+    torch.cuda.synchronize()
+    assert torch.equal(y5[1:3], y2)
+
+
 def test_conv3x3_wino_x3_is_batch_invariant(eng):
     """A frame's result must not depend on the batch it came in (tile boundaries move with the batch): frames 0..2 of a 5-frame call equal
     a 3-frame call bit for bit."""

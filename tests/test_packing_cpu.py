@@ -175,3 +175,33 @@ def test_pow2_prescale_keeps_small_weights_at_22_bits():
         rel_raw = (((raw[:, :, 0] + raw[:, :, 1]).reshape(64, 256) - w).abs() / w.abs())[big]
         if scale <= 1e-3:
             assert float(rel_raw.max()) > 2.0 ** -17             # the unscaled split really is worse there
+
+
+def test_wino_pack_f43_transform():
+    """packing.wino_pack(g=4): the decoded U with the kernel's F(4,3) input and output matrices (wino_x3.hpp header) reproduces the direct 3x3
+    convolution in float64."""
+    import torch.nn.functional as F
+    from mcgaze_amd.packing import wino_pack
+    g = torch.Generator().manual_seed(9)
+    cout, cin, H, W = 128, 32, 4, 8
+    w = torch.randn(cout, cin, 3, 3, generator=g).double()
+    x = torch.randn(2, cin, H, W, generator=g).double()
+    u = wino_pack(w.permute(0, 2, 3, 1).contiguous(), g=4)
+    assert u.numel() * 2 == (cout // 128) * (3 * cin // 16) * 6 * 4 * 2 * 1024
+    v = u.reshape(cout // 128, cin // 16, 3, 6, 4, 2, 2, 32, 8).double().sum(dim=5)      # nt, cs, ky, nu, ct, half, n, e
+    U = v.permute(3, 0, 4, 6, 2, 1, 5, 7).reshape(6, cout, 3, cin)
+    Bt = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+    At = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
+    xp = F.pad(x, (1, 4, 1, 1))
+    y = torch.zeros(2, cout, H, W, dtype=torch.float64)
+    for x0 in range(0, W, 4):
+        for ky in range(3):
+            d = torch.stack([xp[:, :, ky:ky + H, x0 + i] for i in range(6)])                # [6, N, ci, H]
+            V = torch.einsum('pf,fnch->pnch', Bt, d)
+            M = torch.stack([torch.einsum('nch,oc->noh', V[nu], U[nu][:, ky]) for nu in range(6)])
+            Y = torch.einsum('jp,pnoh->jnoh', At, M)
+            for j in range(4):
+                if x0 + j < W:
+                    y[:, :, :, x0 + j] += Y[j]
+    ref = F.conv2d(x, w, padding=1)
+    assert float((y - ref).abs().max()) < 2e-5 * float(ref.abs().max())    # fp16 hi + lo of U: 2^-22 per weight, amplified by the x8 of the output transform
