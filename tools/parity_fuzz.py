@@ -1,6 +1,6 @@
 """GPU tool: parity fuzz of the engines against the CPU oracle on random shapes -- clip length, batch, frame size (multiples of 32),
 per-frame img_shape inside the padded frame, weight seed -- to look for inputs where the parity-grade engines leave north_star's
-1e-3 rad on (yaw, pitch).  usage: python tools/parity_fuzz.py [cases=24] [seed=0] [precisions=f16x3,fp32] [diagnose=1] [family=uniform|trained]"""
+1e-3 rad on (yaw, pitch).  usage: python tools/parity_fuzz.py [cases=24] [seed=0] [precisions=f16x3,fp32] [diagnose=1] [family=uniform|trained] [engine options, e.g. winograd=2]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,6 +16,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 precs = (sys.argv[3] if len(sys.argv) > 3 else 'f16x3,fp32').split(',')
 diagnose = (sys.argv[4] if len(sys.argv) > 4 else '1') != '0'
 family = sys.argv[5] if len(sys.argv) > 5 else 'uniform'   # synth.make_state_dict's weight family
+opts = [kv.partition('=') for kv in sys.argv[6:]]           # mcg_engine_set_option on every engine
 torch.set_num_threads(16)
 engines, sds = {}, {}
 worst = {p: 0.0 for p in precs}
@@ -37,6 +38,8 @@ for c in range(cases):
         key = (p, wseed)
         if key not in engines:
             engines[key] = HipEngine(sds[wseed], precision=p)
+            for name, _, val in opts:
+                engines[key].set_option(name, int(val))
         hw = None if full else np.tile(np.array([ih, iw], dtype=np.int32), (N, 1))
         out = engines[key].forward(torch.from_numpy(img).cuda(), T, img_hw=hw)
         d = float(orc.wrap_yaw(orc.yaw_pitch(out['gaze'][0].cpu()) - want).abs().max())
