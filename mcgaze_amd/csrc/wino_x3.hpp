@@ -19,7 +19,7 @@
 // the input transform + split costs 512 / Nt = 8 VALU per MFMA at Nt = 64, more than a wave can issue beside them.  The 1-D form keeps
 // 4 accumulators per PAIR: a 128-pair x 128-channel tile, 2.7 VALU and 220 bytes per MFMA, one workgroup of 8 waves per CU like tile 50.
 //
-// Structure (the large tile; wino_x3_kernel<NB, RH, RT, CT> has RH x RT row tiles of 32 pairs and CT column tiles of 32 channels).  A
+// Structure (the large tile; wino_x3_kernel<NB, RH, RT, CT, G> has RH x RT row tiles of 32 pairs and CT column tiles of 32 channels).  A
 // workgroup owns 128 consecutive output pairs in raster order over (frame, row, pair) and 128 output channels; wave w computes
 // transform position nu = w & 3 for the row tiles 2 (w >> 2), 2 (w >> 2) + 1 (2 x 4 MFMA tiles = 128 accumulators).  Grids of fewer than
 // ~130 such workgroups (a single clip's P3 / P4 / layer3) run 64 x 64 or 32 x 64 tiles: more workgroups, the same arithmetic per output
@@ -33,7 +33,11 @@
 //     distinct 16-byte bank groups, and a DMA piece still fetches whole 64-byte pixel slices.
 //   * WEIGHTS: per K step (16 channels of one y tap) one 32 KiB stage [nu][channel tile][high, low][lane][16 B], MFMA-fragment-major
 //     and contiguous in global memory in consumption order, through a two-stage ring.
-//   * one s_barrier per K step; everything staged is waited for with vmcnt(0) (two-stage ring: nothing else is in flight).
+//   * one s_barrier per K step; everything staged is waited for with vmcnt(0) (two-stage ring: nothing else is in flight).  A step starts its
+//     MFMAs right behind the barrier and issues the next stage's DMA pieces and the next step's A preparation behind them: the kernel is bound
+//     by what two in-order waves per SIMD can ISSUE (measured: MFMA skeleton 2.0 ms + DMA issue 0.7 + transform 0.37 on the FPN P2 conv), not
+//     by the matrix pipe -- DESIGN.md 3.1h.  Tried and not kept: transposed MFMAs with 16-byte epilogue stores (neutral), one M0 write per four
+//     pieces (neutral), opposite phase orders for the two waves of a SIMD (slower).
 //   * epilogue: the four positions of a pair live in four waves; they meet in LDS (two passes of 64 pairs x 128 channels x 4), the
 //     output transform + bias (+ ReLU) is applied on 16-byte channel chunks and both pixels of a pair are stored.
 // Batch invariance: a pair's arithmetic does not depend on the tile it falls into, so a clip's result is independent of the batch.
