@@ -12,13 +12,16 @@ Semantics kept exactly (pinned by tests/golden/harness_merge.json, produced by r
     score is < 0.5 in either prediction (the stored score may itself be an average);
   * record schema (:210-260): per frame fused gaze, per-clue boxes as [x, y, w, h] or None when zeroed, gazes, scores.
 """
+import collections
 import json
 import math
 import os
 
+import numpy as np
 import torch
 
 CLUES = ('face', 'eyes', 'head')
+last_run_stats = {}       # run_annotation's frame-cache counters of the last call (tools/dataset_throughput.py prints them)
 
 
 def plan_windows(video_length, clip_len=7, stride=4):
@@ -37,48 +40,54 @@ def plan_windows(video_length, clip_len=7, stride=4):
     return out
 
 
-def _zero_low_score_boxes(det, thr):
-    coords, score = det[..., :4], det[..., 4:]
-    return torch.cat([torch.where(score < thr, torch.zeros_like(coords), coords), score], dim=-1)
+def _host(t):
+    """torch tensor (any device) or array -> numpy array on the host (a view where possible)."""
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
 
 def merge_video(windows, clip_outputs, person_threshold=0.5):
-    """windows from plan_windows; clip_outputs[i] = (det_bboxes [T,3,5], fused [T,3], others [T,3,3]) of window i.
-    Returns per-frame (det_bboxes [L,3,5], fused [L,3], others [L,3,3]).  tools/test_gaze360_gaze.py:129-206."""
-    det, fused, others = None, None, None
+    """windows from plan_windows; clip_outputs[i] = (det_bboxes [T,3,5], fused [T,3], others [T,3,3]) of window i (torch tensors or
+    numpy arrays, f32).  Returns per-frame numpy arrays (det_bboxes [L,3,5], fused [L,3], others [L,3,3]).
+    tools/test_gaze360_gaze.py:129-206.  Host arithmetic in f32 -- sums and halvings, exactly rounded, the same bits the reference's
+    torch expressions give; the windows of a video tile it from frame 0 with the last one flush to the end, so frame t of window
+    (start, stop) lands at row start + t."""
+    L = windows[-1][1]
+    det, fused, others = np.empty((L, 3, 5), np.float32), np.empty((L, 3), np.float32), np.empty((L, 3, 3), np.float32)
+    thr = np.float32(person_threshold)
+    half = np.float32(2)
     for i, ((start, stop, overlap), (d, f, o)) in enumerate(zip(windows, clip_outputs)):
-        d = _zero_low_score_boxes(d, person_threshold)
+        d, f, o = _host(d), _host(f), _host(o)
+        low = d[..., 4:] < thr
+        d = np.concatenate([np.where(low, np.float32(0), d[..., :4]), d[..., 4:]], axis=-1)      # boxes of low-score detections are zeroed (:140-150)
         if i == 0:
-            det, fused, others = d.clone(), f.clone(), o.clone()
+            det[:stop], fused[:stop], others[:stop] = d, f, o
             continue
-        T = stop - start
-        new = T - overlap
-        # overlapping frames: last `overlap` stored frames vs the first `overlap` frames of this window
-        old_d, cur_d = det[-overlap:], d[:overlap]
-        bad = (old_d[..., 4:] < person_threshold) | (cur_d[..., 4:] < person_threshold)
-        coords = torch.where(bad, torch.zeros_like(old_d[..., :4]), (old_d[..., :4] + cur_d[..., :4]) / 2)
-        det[-overlap:] = torch.cat([coords, (old_d[..., 4:] + cur_d[..., 4:]) / 2], dim=-1)
-        fused[-overlap:] = (fused[-overlap:] + f[:overlap]) / 2
-        others[-overlap:] = (others[-overlap:] + o[:overlap]) / 2
-        det = torch.cat([det, d[-new:]])
-        fused = torch.cat([fused, f[-new:]])
-        others = torch.cat([others, o[-new:]])
+        # overlapping frames: the last `overlap` stored frames against the first `overlap` frames of this window
+        ov = slice(start, start + overlap)
+        old_d, cur_d = det[ov], d[:overlap]
+        bad = (old_d[..., 4:] < thr) | low[:overlap]
+        det[ov, :, :4] = np.where(bad, np.float32(0), (old_d[..., :4] + cur_d[..., :4]) / half)
+        det[ov, :, 4:] = (old_d[..., 4:] + cur_d[..., 4:]) / half
+        fused[ov] = (fused[ov] + f[:overlap]) / half
+        others[ov] = (others[ov] + o[:overlap]) / half
+        new = slice(start + overlap, stop)
+        det[new], fused[new], others[new] = d[overlap:], f[overlap:], o[overlap:]
     return det, fused, others
 
 
 def video_record(video_id, det, fused, others):
-    """Result record of one video (tools/test_gaze360_gaze.py:210-260)."""
-    det, fused, others = det.detach().cpu(), fused.detach().cpu(), others.detach().cpu()
-    rec = dict(video_id=video_id, category_id=1, fusion_gazes=[])
-    for c in CLUES:
-        rec[f'{c}_bboxes'], rec[f'{c}_gazes'], rec[f'{c}_score'] = [], [], []
-    for t in range(det.shape[0]):
-        rec['fusion_gazes'].append(fused[t].numpy().tolist())
-        for ci, c in enumerate(CLUES):
-            m = det[t, ci, :4].numpy().tolist()
-            rec[f'{c}_bboxes'].append(None if (m[0] + m[1] + m[2] + m[3]) == 0 else [m[0], m[1], m[2] - m[0], m[3] - m[1]])
-            rec[f'{c}_gazes'].append(others[t, ci].numpy().tolist())
-            rec[f'{c}_score'].append(det[t, ci, 4].item())
+    """Result record of one video (tools/test_gaze360_gaze.py:210-260): python floats of the f32 values; a box is [x, y, w, h] with
+    the differences taken in double (the reference subtracts python floats), or None where the four coordinates sum to zero."""
+    det, fused, others = _host(det), _host(fused), _host(others)
+    rec = dict(video_id=video_id, category_id=1, fusion_gazes=fused.tolist())
+    m = det[..., :4].astype(np.float64)
+    empty = (((m[..., 0] + m[..., 1]) + m[..., 2]) + m[..., 3] == 0).tolist()
+    xywh = np.stack([m[..., 0], m[..., 1], m[..., 2] - m[..., 0], m[..., 3] - m[..., 1]], axis=-1).tolist()
+    gazes, score = others.tolist(), det[..., 4].tolist()
+    for ci, c in enumerate(CLUES):
+        rec[f'{c}_bboxes'] = [None if e[ci] else b[ci] for e, b in zip(empty, xywh)]
+        rec[f'{c}_gazes'] = [g[ci] for g in gazes]
+        rec[f'{c}_score'] = [sc[ci] for sc in score]
     return rec
 
 
@@ -101,6 +110,8 @@ def _run_windows(engine, ids, plans, get_window, batch_clips, person_threshold):
     records = [None] * len(plans)
 
     keep = []                                          # pinned host tensors of the last flush: alive until their non-blocking copies ran
+    inflight = collections.deque()                     # batches whose results are on their way to the host: (items, T, pinned buffer, event)
+    spare = []                                         # pinned result buffers free for reuse
 
     def upload(t):
         # small per-batch tables (img_shape, scale_factor): pinned + non-blocking, so that the host does not wait for the device queue to
@@ -111,11 +122,30 @@ def _run_windows(engine, ids, plans, get_window, batch_clips, person_threshold):
         keep.append(p)
         return p.to(dev, non_blocking=True)
 
+    def collect(leave):
+        # results of finished batches -> per-window host arrays -> (once a video's last window is back) merge + record, all on the host:
+        # the consumer never waits for a forward it has just queued (round 3 / 4 did, in video_record's .cpu(): host and device took turns)
+        while len(inflight) > leave or (inflight and (inflight[0][3] is None or inflight[0][3].query())):
+            items, T, buf, ev = inflight.popleft()
+            if ev is not None:
+                ev.synchronize()
+            res = buf[:len(items) * T].numpy().copy()  # [frames, 27] = det 3x5 | fused 3 | others 3x3; copied: the pinned buffer is reused
+            if ev is not None:
+                spare.append(buf)
+            for bi, (vi, wi) in enumerate(items):
+                r = res[bi * T:(bi + 1) * T]
+                outputs[vi][wi] = (r[:, :15].reshape(T, 3, 5), r[:, 15:18], r[:, 18:].reshape(T, 3, 3))
+                pending[vi] -= 1
+                if pending[vi] == 0:                   # all windows of the video are back: merge, record, release
+                    records[vi] = video_record(ids[vi], *merge_video(plans[vi], outputs[vi], person_threshold))
+                    outputs[vi] = None
+
     def flush(key):
         items = buckets.pop(key, [])
         if not items:
             return
         T = key[0]
+        collect(2)
         x = torch.cat([it[2] for it in items]).to(dev, torch.float32).contiguous()
         del keep[:max(0, len(keep) - 4)]
         hw = None if items[0][3] is None else upload(torch.cat([torch.as_tensor(it[3], dtype=torch.int32).reshape(-1, 2) for it in items]))
@@ -123,14 +153,23 @@ def _run_windows(engine, ids, plans, get_window, batch_clips, person_threshold):
         boxes = out['boxes']
         if items[0][4] is not None:   # rescale=True: every frame's boxes by its own scale_factor (multiclue_gaze_roi_head.py:360-363)
             boxes = boxes / upload(torch.cat([torch.as_tensor(it[4], dtype=torch.float32) for it in items]))[:, None, :]
-        det = torch.cat([boxes, out['scores'][..., None]], dim=-1)
-        for bi, (vi, wi, _, _, _) in enumerate(items):
-            sl = slice(bi * T, (bi + 1) * T)
-            outputs[vi][wi] = (det[sl].clone(), out['gaze'][0, sl].clone(), out['gaze'][1:, sl].permute(1, 0, 2).clone())
-            pending[vi] -= 1
-            if pending[vi] == 0:                       # all windows of the video are back: merge, record, release
-                records[vi] = video_record(ids[vi], *merge_video(plans[vi], outputs[vi], person_threshold))
-                outputs[vi] = None
+        n = len(items) * T
+        gaze = out['gaze']
+        packed = torch.cat([boxes.reshape(n, 3, 4), out['scores'].reshape(n, 3, 1)], dim=-1).reshape(n, 15)
+        packed = torch.cat([packed, gaze[0].reshape(n, 3), gaze[1:].permute(1, 0, 2).reshape(n, 9)], dim=1).to(torch.float32)
+        who = [(vi, wi) for vi, wi, _, _, _ in items]
+        if dev.type != 'cuda':
+            inflight.append((who, T, packed, None))
+            return
+        buf = next((b for b in spare if b.shape[0] >= n), None)
+        if buf is not None:
+            spare.remove(buf)
+        else:
+            buf = torch.empty(max(n, batch_clips * T), 27, dtype=torch.float32).pin_memory()
+        buf[:n].copy_(packed, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        inflight.append((who, T, buf, ev))
 
     for vi, plan in enumerate(plans):
         for wi in range(len(plan)):
@@ -141,6 +180,7 @@ def _run_windows(engine, ids, plans, get_window, batch_clips, person_threshold):
                 flush(key)
     for key in sorted(buckets):
         flush(key)
+    collect(0)
     return records
 
 
@@ -214,8 +254,9 @@ def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_cli
             if workers > 0:
                 while state['ahead'] < min(i + len(todo) + lookahead, len(order)):   # decoders stay `lookahead` windows ahead
                     v2, w2 = order[state['ahead']]
-                    cache.prefetch(os.path.join(root, n) if root is not None else n for n in names_of(v2, w2))
+                    cache.prefetch((os.path.join(root, n) if root is not None else n for n in names_of(v2, w2)), flush=False)
                     state['ahead'] += 1
+                cache.flush_requests()
             res = pipeline.run_many([names_of(v2, w2) for v2, w2 in todo], device=engine.device, rng=[rng_of(v2) for v2, _ in todo], img_prefix=root, loader=cache)
             staged.update({i + k: r for k, r in enumerate(res)})
         img, metas = staged.pop(i)
@@ -225,6 +266,7 @@ def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_cli
     try:
         return _run_windows(engine, [v['id'] for v in videos], plans, get_window, batch_clips, person_threshold)
     finally:
+        last_run_stats.update(decodes=cache.decodes, decode_waits=cache.waits, decode_wait_s=round(cache.wait_s, 3), decode_first_wait_s=round(cache.first_wait_s, 3))
         cache.close()
 
 

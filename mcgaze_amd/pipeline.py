@@ -23,6 +23,7 @@ import concurrent.futures
 import ctypes as C
 import os
 import threading
+import time
 
 import numpy as np
 import torch
@@ -78,8 +79,9 @@ class _DecodeProcs:
         import sys
         worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_decode_worker.py')
         self.procs = [subprocess.Popen([sys.executable, worker, ring_path, str(slot_bytes)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                       text=True, bufsize=1) for _ in range(n)]
+                                       text=True) for _ in range(n)]
         self.pending = [collections.deque() for _ in range(n)]
+        self.dirty = set()                                       # processes with requests still in this side's stdin buffer (see flush)
         self.threads = [threading.Thread(target=self._reader, args=(k,), daemon=True, name=f'mcg-decode-{k}') for k in range(n)]
         for t in self.threads:
             t.start()
@@ -98,11 +100,19 @@ class _DecodeProcs:
     def submit(self, path, offset):
         if '\n' in path:
             raise ValueError('file names with newlines cannot go to the decode workers')
-        k = min(range(len(self.procs)), key=lambda i: len(self.pending[i]))
+        lens = [len(q) for q in self.pending]
+        k = lens.index(min(lens))
         fut = concurrent.futures.Future()
         self.pending[k].append(fut)
-        self.procs[k].stdin.write(f'{offset} {path}\n')
+        self.procs[k].stdin.write(f'{offset} {path}\n')          # buffered: one pipe write per flush(), not per request
+        self.dirty.add(k)
         return fut
+
+    def flush(self):
+        """Hand the buffered requests to the workers.  Must run before anybody waits for one of their futures."""
+        for k in self.dirty:
+            self.procs[k].stdin.flush()
+        self.dirty.clear()
 
     def close(self):
         for p in self.procs:
@@ -144,9 +154,11 @@ class FrameCache:
                 raise ValueError('FrameCache(processes=True) decodes with its own worker (PIL, RGB)')
             import tempfile
             fd, self.ring_path = tempfile.mkstemp(prefix='mcg_ring_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+            import mmap
             os.ftruncate(fd, (self.capacity + 1) * self.slot_bytes)
+            self._map = mmap.mmap(fd, (self.capacity + 1) * self.slot_bytes)
             os.close(fd)
-            self.ring = np.memmap(self.ring_path, dtype=np.uint8, mode='r+')
+            self.ring = np.frombuffer(self._map, dtype=np.uint8)   # a plain ndarray: np.memmap's subclass machinery cost 5 us per slice
             self.free = list(range(self.capacity + 1))
             self.procs = _DecodeProcs(int(workers), self.ring_path, self.slot_bytes)
         elif workers > 0:
@@ -155,6 +167,7 @@ class FrameCache:
         self.used = collections.OrderedDict()       # paths the consumer has already asked for, oldest use first: the eviction candidates
         self.lock = threading.Lock()
         self.decodes = 0
+        self.waits, self.wait_s, self.first_wait_s = 0, 0.0, 0.0            # times the consumer found a frame not decoded yet, and how long it then waited
 
     def _entry(self, path, wanted_now):
         with self.lock:
@@ -190,26 +203,55 @@ class FrameCache:
                 victim = p
         old = self.items.pop(victim) if victim is not None else self.items.popitem(last=False)[1]
         if isinstance(old, tuple):                               # ring slot: its writer must be done before the slot is handed out again
+            if not old[0].done():
+                self.procs.flush()
             try:
                 old[0].result()
             except Exception:
                 pass
             self.free.append(old[1])
 
-    def prefetch(self, paths):
+    def prefetch(self, paths, flush=True):
+        """Start decoding ``paths`` ahead of their use.  flush=False leaves the requests of helper processes in this side's pipe buffers
+        (one write per process for a whole batch of prefetch calls): follow with ``flush_requests()``."""
         if self.pool is not None or self.procs is not None:
             for p in paths:
                 self._entry(p, False)
+            if flush and self.procs is not None:
+                self.procs.flush()
+
+    def flush_requests(self):
+        if self.procs is not None:
+            self.procs.flush()
+
+    def _wait(self, fut):
+        if fut.done():
+            return fut.result()
+        if self.procs is not None:
+            self.procs.flush()
+        t0 = time.perf_counter()
+        r = fut.result()
+        dt = time.perf_counter() - t0
+        if self.waits == 0:
+            self.first_wait_s = dt                               # mostly the helpers' start-up (interpreter + numpy + PIL imports)
+        self.waits += 1
+        self.wait_s += dt
+        return r
 
     def __call__(self, path):
-        e = self._entry(path, True)
+        e = self.items.get(path)
+        if e is None:
+            e = self._entry(path, True)
+        else:                                                    # the common case (decoded ahead), without _entry's bookkeeping
+            self.used[path] = True
+            self.used.move_to_end(path)
         if isinstance(e, tuple):                                 # decoded by a helper process into ring slot e[1]
-            h, w = e[0].result()
+            h, w = self._wait(e[0])
             if h == 0:
                 return self.loader(path)                         # larger than a slot: decoded here
             o = e[1] * self.slot_bytes
             return self.ring[o:o + h * w * 3].reshape(h, w, 3)
-        return e.result() if isinstance(e, concurrent.futures.Future) else e
+        return self._wait(e) if isinstance(e, concurrent.futures.Future) else e
 
     def close(self):
         if self.pool is not None:
@@ -220,7 +262,8 @@ class FrameCache:
         self.items.clear()
         self.used.clear()
         if self.ring_path is not None:
-            self.ring = None
+            self.ring = None                                     # (views handed out earlier keep the mapping alive; it goes with the last of them)
+            self._map = None
             try:
                 os.unlink(self.ring_path)
             except OSError:
@@ -242,6 +285,12 @@ class CenterCrop:
         else:
             assert 0 < crop_size[0] <= 1 and 0 < crop_size[1] <= 1
         self.crop_size, self.crop_type, self.crop_u = crop_size, crop_type, crop_u
+        if crop_type == 'relative_range':
+            # upstream: cs = float32 array, u = float64 array -> cs + u * (1 - cs) with (1 - cs) rounded in f32 and the rest in f64.
+            # The same values as python floats (one rounding per operation, like the array expression), without three array temporaries per frame.
+            cs = np.asarray(crop_size, dtype=np.float32)
+            self._cs = [float(v) for v in cs]
+            self._rest = [float(v) for v in (1 - cs)]
 
     def _get_crop_size(self, h, w, rng):
         if self.crop_type == 'absolute':
@@ -253,9 +302,8 @@ class CenterCrop:
             return crop_h, crop_w
         if self.crop_type == 'relative':
             return int(h * self.crop_size[0] + 0.5), int(w * self.crop_size[1] + 0.5)
-        cs = np.asarray(self.crop_size, dtype=np.float32)
-        u = rng.rand(1) if self.crop_u is None else np.asarray([self.crop_u], dtype=np.float64)
-        crop_h, crop_w = cs + u * (1 - cs)
+        u = float(rng.rand(1)[0]) if self.crop_u is None else float(self.crop_u)      # ONE uniform for both sides (:1126-1130)
+        crop_h, crop_w = self._cs[0] + u * self._rest[0], self._cs[1] + u * self._rest[1]
         return int(h * crop_h + 0.5), int(w * crop_w + 0.5)
 
     def plan(self, p, rng):
@@ -398,6 +446,11 @@ class Collect:
         return {k: getattr(p, k) for k in self.meta_keys}
 
 
+_DESC = np.dtype([('src', np.uint64)] + [(f, np.int32) for f in ('src_h', 'src_w', 'src_pitch', 'crop_y', 'crop_x', 'crop_h', 'crop_w', 'out_h', 'out_w')],
+                 align=True)                       # lib.FrameDesc / mcg_frame_desc, as a numpy record
+assert _DESC.itemsize == C.sizeof(L.FrameDesc) and all(_DESC.fields[n][1] == getattr(L.FrameDesc, n).offset for n in _DESC.names)
+
+
 class DevicePipeline:
     """``Compose(cfg.data.test.pipeline)`` (mmdet/datasets/pipelines/compose.py:11-51) whose pixel work is one HIP launch."""
 
@@ -507,13 +560,19 @@ class DevicePipeline:
             for a, o in zip(arrays, offs):
                 host_np[int(o):int(o) + a.size] = a.reshape(-1)
             raw = torch.empty(total, dtype=torch.uint8, device=dev)
+            # descriptors (mcg_frame_desc), built as one structured array per padded size
+            src_a = np.asarray(src, dtype=np.int64)
+            shp = np.asarray([a.shape[:2] for a in arrays], dtype=np.int32)
+            geo = np.asarray([p.crop + p.img_shape[:2] for p in plans], dtype=np.int32)          # crop y, x, h, w, out h, w
             for pad, wis in groups.items():
-                idx = [k for wi in wis for k in range(bounds[wi], bounds[wi + 1])]
-                desc = (L.FrameDesc * len(idx))()
-                for i, k in enumerate(idx):
-                    a, p = arrays[src[k]], plans[k]
-                    desc[i] = L.FrameDesc(raw.data_ptr() + int(offs[src[k]]), a.shape[0], a.shape[1], a.shape[1] * 3, *p.crop, p.img_shape[0], p.img_shape[1])
-                host_np[desc_off[pad]:desc_off[pad] + len(idx) * dsz] = np.frombuffer(desc, dtype=np.uint8)
+                idx = np.concatenate([np.arange(bounds[wi], bounds[wi + 1]) for wi in wis])
+                si = src_a[idx]
+                desc = np.zeros(len(idx), dtype=_DESC)
+                desc['src'] = raw.data_ptr() + offs[si]
+                desc['src_h'], desc['src_w'], desc['src_pitch'] = shp[si, 0], shp[si, 1], shp[si, 1] * 3
+                for j, f in enumerate(('crop_y', 'crop_x', 'crop_h', 'crop_w', 'out_h', 'out_w')):
+                    desc[f] = geo[idx, j]
+                host_np[desc_off[pad]:desc_off[pad] + len(idx) * dsz] = desc.view(np.uint8)
             raw.copy_(host[:total], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))

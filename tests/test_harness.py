@@ -120,6 +120,9 @@ def test_run_annotation_from_files_equals_window_by_window(tmp_path):
     recs = harness.run_annotation(e, anno, str(tmp_path), pipe, batch_clips=3, rng=np.random.RandomState(21))   # in-line decode, cached
     for workers, lookahead in ((8, None), (3, 1)):   # decode threads ahead of the GPU / a short look-ahead with evictions: the records may not depend on it
         assert harness.run_annotation(e, anno, str(tmp_path), pipe, batch_clips=3, rng=np.random.RandomState(21), workers=workers, lookahead=lookahead) == recs
+    for workers, lookahead in ((4, None), (2, 1)):   # the same with decode helper PROCESSES (shared-memory ring)
+        assert harness.run_annotation(e, anno, str(tmp_path), pipe, batch_clips=3, rng=np.random.RandomState(21), workers=workers, lookahead=lookahead,
+                                      processes=True) == recs
     rng = np.random.RandomState(21)
     for v, rec in zip(anno['videos'], recs):
         plan = harness.plan_windows(len(v['file_names']))
@@ -132,6 +135,32 @@ def test_run_annotation_from_files_equals_window_by_window(tmp_path):
             outs.append((det.clone(), o['gaze'][0].clone(), o['gaze'][1:].permute(1, 0, 2).clone()))
         want = harness.video_record(v['id'], *harness.merge_video(plan, outs))
         assert rec == want and len(rec['fusion_gazes']) == len(v['file_names'])
+
+
+def test_frame_cache_helper_processes(tmp_path):
+    """pipeline.FrameCache(processes=True): frames decoded by the helper processes (mcgaze_amd/_decode_worker.py, shared-memory ring) are
+    the in-line decoder's pixels; a frame larger than a ring slot is decoded in line; a missing file raises where the frame is asked
+    for; eviction under a small capacity hands slots out again without mixing frames up."""
+    from PIL import Image
+    from mcgaze_amd.pipeline import FrameCache, LoadImageFromFile
+    rs = np.random.RandomState(3)
+    paths = []
+    for i, shape in enumerate([(40, 50, 3), (64, 64, 3), (33, 70, 3), (40, 50), (90, 120, 3), (40, 50, 3), (12, 12, 3), (50, 40, 3)]):
+        paths.append(str(tmp_path / f'{i}.png'))
+        Image.fromarray(rs.randint(0, 256, shape).astype(np.uint8)).save(paths[-1])      # index 3: a grey image (converted to RGB by both decoders)
+    want = [LoadImageFromFile.load(p, rgb=True) for p in paths]
+    cache = FrameCache(workers=3, capacity=4, processes=True, slot_bytes=64 * 64 * 3)      # the 90x120 frame does not fit a slot
+    try:
+        for rounds in range(2):
+            cache.prefetch(paths[:4])
+            for k in (0, 1, 2, 3, 4, 5, 6, 7, 2, 0):
+                got = cache(paths[k])
+                assert got.dtype == np.uint8 and got.shape == want[k].shape and np.array_equal(got, want[k]), k
+        assert cache.decodes >= len(paths)
+        with pytest.raises(RuntimeError, match='decode worker'):
+            cache(str(tmp_path / 'absent.png'))
+    finally:
+        cache.close()
 
 
 def test_dataset_tool_cli_and_sharding():

@@ -58,7 +58,7 @@ with tempfile.TemporaryDirectory() as tmp:
     nwin = sum(len(harness.plan_windows(L)) for _ in range(V))
     print(f'{V} videos x {L} frames of {S}x{S} JPEG = {V * L} frames, {nwin} windows, engine {prec}', flush=True)
     ref = None
-    for workers, procs in (((0, False), (8, True)) if K > 0 else ((0, False), (8, False), (8, True), (16, True), (0, False), (12, True))):
+    for workers, procs in (((8, True),) if os.environ.get('MCG_PROFILE') else ((0, False), (8, True)) if K > 0 else ((0, False), (8, False), (8, True), (16, True), (0, False), (12, True))):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         recs = harness.run_annotation(eng, anno, tmp, pipe, rng=np.random.RandomState(1), workers=workers, processes=procs)
@@ -66,7 +66,7 @@ with tempfile.TemporaryDirectory() as tmp:
         dt = time.perf_counter() - t0
         ref = ref or recs
         kind = 'processes' if procs else ('threads' if workers else 'in line')
-        print(f'workers={workers:2d} ({kind:9s}): {dt:6.2f} s  {V * L / dt:8.1f} frames/s  {nwin / dt:7.1f} windows/s  identical={recs == ref}', flush=True)
+        print(f'workers={workers:2d} ({kind:9s}): {dt:6.2f} s  {V * L / dt:8.1f} frames/s  {nwin / dt:7.1f} windows/s  identical={recs == ref}  {harness.last_run_stats}', flush=True)
     if K > 0:
         json.dump(anno, open(os.path.join(tmp, 'anno.json'), 'w'))
         t0 = time.perf_counter()
@@ -102,4 +102,4 @@ with tempfile.TemporaryDirectory() as tmp:
         harness.run_annotation(eng, anno, tmp, pipe, rng=np.random.RandomState(1), workers=16, processes=True)
         torch.cuda.synchronize()
         pr.disable()
-        pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
