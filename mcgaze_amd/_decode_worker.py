@@ -1,36 +1,65 @@
 """Decode worker of pipeline.FrameCache(processes=True).  Started as a plain child process (`python _decode_worker.py <ring file> <slot
-bytes>`, not through multiprocessing: no fork of a process that holds a HIP context, no re-import of the caller's main module, and
-this file imports neither torch, numpy nor the package), it reads one request per line on stdin -- "<byte offset> <path>" -- decodes the file
-with PIL and writes the RGB uint8 pixels into the memory-mapped ring file (/dev/shm) at that offset, then answers "<h> <w>" on stdout
-("-1 <message>" on failure, "0 0" when the frame does not fit a slot: the consumer then decodes it in line).  Only what the host side of
-the test pipeline did in line before (LoadImageFromFile.load, mmdet/datasets/pipelines/loading.py:36-82) -- no arithmetic of the hot path."""
+bytes> <control file> <k> <n> <records per queue> <slots>`, not through multiprocessing: no fork of a process that holds a HIP context, no
+re-import of the caller's main module, and this file imports neither torch, numpy nor the package).  It serves queue ``k`` of the
+mailbox pipeline._DecodeProcs lays out in the control file: a request record names a ring slot and a path; the file is decoded with
+PIL, its RGB uint8 pixels go into the memory-mapped ring file (/dev/shm) at that slot, then h, w and LAST the state word of the slot
+are written (1 = done; 2 = the frame does not fit a slot, the consumer decodes it in line; 3 = failed, the message is in the slot).  The
+queue is polled (200 us naps while it is empty, 1 ms after 40 ms of idleness); the loop ends when the stop word is set or the parent
+is gone.  Only what the host side of the test pipeline did in line before (LoadImageFromFile.load,
+mmdet/datasets/pipelines/loading.py:36-82) -- no arithmetic of the hot path."""
 import mmap
 import os
+import struct
 import sys
+import time
+
+REC = 1024                             # pipeline._DecodeProcs.REC
 
 
 def main():
-    from PIL import Image          # no numpy here: its import alone is 0.2 s of start-up per helper; PIL hands out the pixel bytes itself
-    fd = os.open(sys.argv[1], os.O_RDWR)
+    from PIL import Image              # no numpy here: its import alone is 0.2 s of start-up per helper; PIL hands out the pixel bytes itself
+    ring_path, slot_bytes, ctl_path, k, n, R, slots = sys.argv[1], int(sys.argv[2]), sys.argv[3], *map(int, sys.argv[4:8])
+    fd = os.open(ring_path, os.O_RDWR)
     ring = mmap.mmap(fd, 0)
     os.close(fd)
-    slot_bytes = int(sys.argv[2])
-    out = sys.stdout
-    for line in sys.stdin:
-        off, path = line.rstrip('\n').split(' ', 1)
+    fd = os.open(ctl_path, os.O_RDWR)
+    ctl = mmap.mmap(fd, 0)
+    os.close(fd)
+    req_base = (64 + n * 128 + 4095) // 4096 * 4096
+    stat_base = req_base + n * R * REC
+    head_off, tail_off = 64 + k * 128, 64 + k * 128 + 64
+    parent = os.getppid()
+    tail, idle = 0, 0
+    while True:
+        if struct.unpack_from('<q', ctl, head_off)[0] == tail:
+            if struct.unpack_from('<q', ctl, 0)[0] or os.getppid() != parent:
+                break
+            idle += 1
+            time.sleep(0.0002 if idle < 200 else 0.001)
+            continue
+        idle = 0
+        off = req_base + (k * R + tail % R) * REC
+        slot, plen = struct.unpack_from('<qi', ctl, off)
+        path = os.fsdecode(ctl[off + 12:off + 12 + plen])
+        st = stat_base + slot * 16
         try:
             with Image.open(path) as im:
                 rgb = im.convert('RGB')
                 w, h = rgb.size
                 if h * w * 3 > slot_bytes:
-                    out.write('0 0\n')
+                    state = 2
                 else:
-                    o = int(off)
-                    ring[o:o + h * w * 3] = rgb.tobytes()      # rows of RGB triples: what np.asarray(rgb) holds
-                    out.write(f'{h} {w}\n')
-        except Exception as e:   # reported to the consumer, which raises it where the frame is asked for
-            out.write('-1 ' + repr(e).replace('\n', ' ') + '\n')
-        out.flush()
+                    ring[slot * slot_bytes:slot * slot_bytes + h * w * 3] = rgb.tobytes()      # rows of RGB triples: what np.asarray(rgb) holds
+                    struct.pack_into('<ii', ctl, st + 4, h, w)
+                    state = 1
+        except Exception as e:         # reported to the consumer, which raises it where the frame is asked for
+            msg = repr(e).replace('\n', ' ').encode('utf-8', 'replace')[:slot_bytes]
+            ring[slot * slot_bytes:slot * slot_bytes + len(msg)] = msg
+            struct.pack_into('<i', ctl, st + 12, len(msg))
+            state = 3
+        struct.pack_into('<i', ctl, st, state)                   # last: the consumer polls this word
+        tail += 1
+        struct.pack_into('<q', ctl, tail_off, tail)
 
 
 if __name__ == '__main__':

@@ -254,9 +254,8 @@ def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_cli
             if workers > 0:
                 while state['ahead'] < min(i + len(todo) + lookahead, len(order)):   # decoders stay `lookahead` windows ahead
                     v2, w2 = order[state['ahead']]
-                    cache.prefetch((os.path.join(root, n) if root is not None else n for n in names_of(v2, w2)), flush=False)
+                    cache.prefetch(os.path.join(root, n) if root is not None else n for n in names_of(v2, w2))
                     state['ahead'] += 1
-                cache.flush_requests()
             res = pipeline.run_many([names_of(v2, w2) for v2, w2 in todo], device=engine.device, rng=[rng_of(v2) for v2, _ in todo], img_prefix=root, loader=cache)
             staged.update({i + k: r for k, r in enumerate(res)})
         img, metas = staged.pop(i)
