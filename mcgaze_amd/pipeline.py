@@ -483,8 +483,10 @@ class DevicePipeline:
             raise ValueError(f'unsupported test pipeline {kinds}: need ... Normalize ... DefaultFormatBundle, Collect')
         self.collect = self.transforms[-1]
         self._planners = [t.plan for t in self.transforms if type(t) not in (LoadImageFromFile, ImageToTensor, Collect)]   # the rest plan nothing
-        self._scratch = {}
-        self._pin, self._pin_ev, self._pin_i = [None, None], [None, None], 0   # pinned staging buffers (two, alternating) and their copy-done events
+        # upload stages, used in turn: a pinned host buffer, its device twin, the event of the copy between them (on the copy stream) and the
+        # event of the pixel kernels that read the device twin (on the caller's stream)
+        self._stages = [dict(pin=None, dev=None, copied=None, read=None) for _ in range(self.STAGES)]
+        self._stage_i, self._copy_stream = 0, {}
 
     def plan(self, shape, rng=np.random, filename=None, ori_filename=None):
         p = FramePlan(shape, filename, ori_filename)
@@ -502,15 +504,28 @@ class DevicePipeline:
         loader: path -> HxWx3 uint8 array (default LoadImageFromFile.load; a FrameCache decodes ahead on host threads)."""
         return self.run_many([frames], device, rng, img_prefix, stream, loader)[0]
 
-    def _staging(self, nbytes, dev):
-        """A pinned host buffer of at least nbytes, one of two that alternate: the copy out of the other may still be in flight.
-        (A fresh ``pin_memory()`` per call costs milliseconds once decode threads compete for the allocator.)"""
-        i = self._pin_i = (self._pin_i + 1) & 1
-        if self._pin_ev[i] is not None:
-            self._pin_ev[i].synchronize()
-        if self._pin[i] is None or self._pin[i].numel() < nbytes:
-            self._pin[i] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8).pin_memory()
-        return i, self._pin[i]
+    STAGES = 4
+
+    def _staging(self, nbytes, dev, main):
+        """The next upload stage, its buffers at least nbytes large: a pinned host buffer (a fresh ``pin_memory()`` per call costs
+        milliseconds once decode threads compete for the allocator) and a device buffer that only the copy stream writes and only the
+        pixel kernels read.  The upload runs on a stream of its own: on the caller's stream it would queue behind the forwards already
+        launched there and the PCIe transfer would take its turn with the compute instead of running under it.  STAGES of them, used in
+        turn, so that the host fills stage i while the copies and kernels of the stages before it are still queued."""
+        st = self._stages[self._stage_i]
+        self._stage_i = (self._stage_i + 1) % self.STAGES
+        if st['copied'] is not None:
+            st['copied'].synchronize()                            # the pinned buffer is about to be overwritten
+        cs = self._copy_stream.get(dev)
+        if cs is None:
+            cs = self._copy_stream[dev] = torch.cuda.Stream(dev)
+        if st['pin'] is None or st['pin'].numel() < nbytes or st['dev'].device != dev:
+            size = max(int(nbytes * 1.25), 1 << 20)
+            st['pin'] = torch.empty(size, dtype=torch.uint8).pin_memory()
+            st['dev'] = torch.empty(size, dtype=torch.uint8, device=dev)
+            st['read'] = None
+            cs.wait_stream(main)                                  # the allocator may hand out memory that work queued on `main` still uses
+        return st, cs
 
     def run_many(self, windows, device='cuda:0', rng=np.random, img_prefix=None, stream=None, loader=None):
         """Several clip batches (windows) through ONE staging copy and one launch per distinct padded size: windows = list of lists
@@ -576,11 +591,12 @@ class DevicePipeline:
             desc_off[pad] = total
             total += (sum(bounds[wi + 1] - bounds[wi] for wi in wis) * dsz + 255) // 256 * 256
         with torch.cuda.device(dev):
-            slot, host = self._staging(total, dev)
+            main = torch.cuda.current_stream(dev) if stream is None else torch.cuda.ExternalStream(stream, device=dev)
+            st, cs = self._staging(total, dev, main)
+            host, raw = st['pin'], st['dev']
             host_np = host.numpy()
             for a, o in zip(arrays, offs):
                 host_np[int(o):int(o) + a.size] = a.reshape(-1)
-            raw = torch.empty(total, dtype=torch.uint8, device=dev)
             # descriptors (mcg_frame_desc), built as one structured array per padded size
             src_a = np.asarray(src, dtype=np.int64)
             shp = np.asarray([a.shape[:2] for a in arrays], dtype=np.int32)
@@ -594,16 +610,18 @@ class DevicePipeline:
                 for j, f in enumerate(('crop_y', 'crop_x', 'crop_h', 'crop_w', 'out_h', 'out_w')):
                     desc[f] = geo[idx, j]
                 host_np[desc_off[pad]:desc_off[pad] + len(idx) * dsz] = desc.view(np.uint8)
-            raw.copy_(host[:total], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            self._pin_ev[slot] = ev
+            if st['read'] is not None:
+                cs.wait_event(st['read'])                         # the kernels that read this device buffer STAGES calls ago
+            with torch.cuda.stream(cs):
+                raw[:total].copy_(host[:total], non_blocking=True)
+            st['copied'] = torch.cuda.Event()
+            st['copied'].record(cs)
+            main.wait_event(st['copied'])
         norm = plans[0].img_norm_cfg
         mean = (C.c_float * 3)(*[float(v) for v in norm['mean']])
         stdinv = (C.c_float * 3)(*[float(np.float32(1.0 / np.float64(v))) for v in norm['std']])
         swap = int(bool(norm['to_rgb']) != rgb_source)        # channel swap the kernel performs: wanted order differs from the source's
-        keep = [raw]
-        s = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        s = main.cuda_stream
         for (pad_h, pad_w), wis in groups.items():
             n_idx = sum(bounds[wi + 1] - bounds[wi] for wi in wis)
             img = torch.empty(n_idx, 3, pad_h, pad_w, dtype=torch.float32, device=dev)
@@ -614,7 +632,8 @@ class DevicePipeline:
                 cnt = bounds[wi + 1] - bounds[wi]
                 out[wi] = (img[at:at + cnt], [self.collect.meta(p) for p in plans[bounds[wi]:bounds[wi + 1]]])
                 at += cnt
-        self._scratch = dict(keep=keep)                       # keep the inputs alive until the stream has consumed them
+        st['read'] = torch.cuda.Event()
+        st['read'].record(main)
         return out
 
 
