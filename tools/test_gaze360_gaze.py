@@ -53,9 +53,9 @@ def parse_args(argv=None):
     ap.add_argument('--seed', type=int, default=None)
     ap.add_argument('--per-video-seed', action='store_true',
                     help='seed the crop draws per VIDEO (seed + video id) instead of one generator per process: the records then do not depend on the number of ranks')
-    ap.add_argument('--workers', type=int, default=8, help='decode helpers that run ahead of the GPU (0 = decode in line); 8 processes measured 3 430 frames/s against 1 500 in line')
+    ap.add_argument('--workers', type=int, default=8, help='decode helpers that run ahead of the GPU (0 = decode in line); 8 processes measured 9 500 - 9 800 frames/s against 1 900 - 2 000 in line (DESIGN.md section 4)')
     ap.add_argument('--decode', default='processes', choices=['processes', 'threads'], help="kind of decode helper: child processes writing into a /dev/shm ring (default), or host threads")
-    ap.add_argument('--ranks-per-gpu', type=int, default=1, help='with torch.distributed.run: consecutive ranks that share one GPU (the consumer loop of one process feeds ~3 400 frames/s; the engine takes five times that)')
+    ap.add_argument('--ranks-per-gpu', type=int, default=1, help='with torch.distributed.run: consecutive ranks that share one GPU (one consumer process now keeps the device ~80 % busy: more than one per GPU measured slower on the MI355X box; kept for hosts with slower cores)')
     ap.add_argument('--anno', default=None, help='ground-truth annotation json: print the MAE')
     ap.add_argument('--setting', default=None, choices=['gaze360', 'l2cs'], help='metric variant (default: from the config name)')
     a = ap.parse_args(argv)
@@ -81,14 +81,18 @@ def main(argv=None):
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
     print(time.strftime('%Y-%m-%d %H:%M:%S', time.localtime(time.time())))
+    t_start = time.time()
     model = init_detector(a.config, a.checkpoint, device=device, cfg_options=a.cfg_options, precision=a.precision)
     pipe = DevicePipeline(model.cfg.data.test.pipeline)
     anno = json.load(open(a.json))
     idx = shard_videos(anno['videos'], world, rank)
+    t_init = time.time()
     rng = np.random.RandomState(a.seed + rank) if a.seed is not None else None
     recs = harness.run_annotation(model.engine(), dict(videos=[anno['videos'][i] for i in idx]), a.root, pipe, batch_clips=a.batch_clips, rng=rng, workers=a.workers,
                                   processes=a.decode == 'processes',
                                   video_rng=(lambda vid: np.random.RandomState(((a.seed or 0) * 1000003 + int(vid)) & 0x7fffffff)) if a.per_video_seed else None)
+    torch.cuda.synchronize()
+    t_run = time.time()
     if world > 1:
         recs = gather_records(idx, recs, len(anno['videos']))
     if rank == 0:
@@ -97,6 +101,10 @@ def main(argv=None):
         if a.anno:
             setting = a.setting or ('l2cs' if 'l2cs' in os.path.basename(a.config) else 'gaze360')
             metric.gaze_error(recs, json.load(open(a.anno)), 'fusion_gazes', setting=setting)
+    if rank == 0:
+        frames = sum(len(anno['videos'][i]['file_names']) for i in idx)
+        print(f'[mcgaze_amd] model + annotation {t_init - t_start:.2f} s, inference {t_run - t_init:.2f} s ({frames / max(t_run - t_init, 1e-9):.0f} frames/s on this rank), '
+              f'gather + result file + metric {time.time() - t_run:.2f} s', file=sys.stderr)
     print(time.strftime('%Y-%m-%d %H:%M:%S', time.localtime(time.time())))
     if world > 1:
         import torch.distributed as dist
