@@ -295,6 +295,8 @@ void mcg_engine_destroy(mcg_engine* e);
  *   pointwise_stream  0/1 HBM-bound 1x1 convs (layer2, layer3 conv3, P2 / P3 laterals) by the persistent register-resident-weight
  *                     kernel pw_single.hpp (bf16; default 1)
  *   bottleneck_fused  0/1 the fused bottleneck tails handed over in mcg_model_weights.fused (f16x3; default 1)
+ *   bottleneck_blocked 0/1 a tensor that only travels from one fused tail to the next (the residual inside layer1 / layer2) is kept in that
+ *                     kernel's blocked layout (whole-line stores and loads) instead of [M][C]; internal workspace only, results bit-identical (default 1)
  *   winograd          0/1/2 stride-1 3x3 convs that carry a Winograd copy by wino_x3.hpp (f16x3): 0 off, 1 (default) F(2,3) (mcg_conv_weights.wf), 2 F(4,3)
  *                     on maps whose shape allows it (mcg_conv_weights.wf4; 6 % faster there, four times the operator error), F(2,3) elsewhere
  *   range_audit       0/1 DEBUG (MCG_F32 / MCG_F16X3; default 0): after every activation tensor the trunk writes, a counting kernel tallies the

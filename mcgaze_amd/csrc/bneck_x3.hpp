@@ -55,6 +55,8 @@ struct BneckParams {
   float* y;              // [M][C]
   float* z;              // [M][CN] (CN > 0)
   int H, W, tiles_x, tiles_per_frame, total_tiles;
+  int res_blocked, y_blocked;  // the residual / y tensor is in the kernel's own BLOCKED layout (below) instead of [M][C]: only between two launches of
+                               // this kernel over the same H x W grid (engine.hip: the blocks inside layer1 / layer2); NSRC == 1 only for the residual
   unsigned long long* trace;   // optional (measurement aid): workgroup 0 writes s_memtime stamps -- [0..2047] compute wave 0 (tile start, after
                                // conv2, after each chunk), [2048..4095] the loader wave (each slab's arrival); NULL in the product path
 };
@@ -241,6 +243,14 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
     const bool valid = gy < p.H && gx < p.W;
     const bool st_ok = valid, ld_ok = valid;
     const long long row = ((long long)n * p.H + (valid ? gy : 0)) * p.W + (valid ? gx : 0);
+    // Residual / y addressing.  [M][C]: a lane's 16-byte piece of (chunk oc, channel tile c, quad q) is at row * C + 64 oc + 32 c + 8 q + 4 half -- one
+    // instruction touches 32 rows, 32 bytes of each (the two lane halves adjacent).  BLOCKED: per (tile, pixel group) a block of 32 x C floats ordered
+    // [oc][c][q][pixel][half][4], so the 64 lanes of one instruction write ONE contiguous KiB -- eight whole lines instead of 32 quarter lines.
+    // Measured on the layer1 identity block: a CU moves 11.5 B/clk with the quarter-line pattern, 18.5 with whole lines.
+    const long long blk = ((long long)tile * NG + g) * (32 * C) + pl * 8 + 4 * half;
+    const long long rbase = p.res_blocked ? blk : row * C + 4 * half, ybase = p.y_blocked ? blk : row * C + 4 * half;
+    const int r_so = p.res_blocked ? 2048 : 64, r_sc = p.res_blocked ? 1024 : 32, r_sq = p.res_blocked ? 256 : 8;
+    const int y_so = p.y_blocked ? 2048 : 64, y_sc = p.y_blocked ? 1024 : 32, y_sq = p.y_blocked ? 256 : 8;
     const int next = tile + stride;
     const bool has_next = next < p.total_tiles;
 
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          rres[SL][c][q] = ld_ok ? *(const float4*)(p.res + row * C + chunk * 64 + c * 32 + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+          rres[SL][c][q] = ld_ok ? *(const float4*)(p.res + rbase + chunk * r_so + c * r_sc + q * r_sq) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     if constexpr (NSRC == 1) {
       static_for<RD>([&](auto d) { res_load(d, decltype(d)::value); });
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
           float4 o = make_float4(acc2[c][4 * q] * ws3 + b.x, acc2[c][4 * q + 1] * ws3 + b.y, acc2[c][4 * q + 2] * ws3 + b.z, acc2[c][4 * q + 3] * ws3 + b.w);
           if constexpr (NSRC == 1) { const float4 r = rres[SLOT][c][q]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
           o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-          if (st_ok) *(float4*)(p.y + row * C + ch) = o;
+          if (st_ok) *(float4*)(p.y + ybase + oc * y_so + c * y_sc + q * y_sq) = o;
           acc2[c][4 * q] = o.x; acc2[c][4 * q + 1] = o.y; acc2[c][4 * q + 2] = o.z; acc2[c][4 * q + 3] = o.w;
         }
       if constexpr (NSRC == 1) {

@@ -36,6 +36,7 @@ struct mcg_engine {
   mcg_conv_weights lateral[4], fpn_out[4], c3_ds[4];
   std::vector<mcg_fused_block> fused;   // f16x3: fused bottleneck tails (bneck_x3.hpp), looked up by conv2 index
   bool bneck_fused = true;
+  bool bneck_blocked = true;            // tensors that only travel between two fused tails use the kernel's blocked layout (bneck_x3.hpp)
   int winograd = 1;            // f16x3: stride-1 3x3 convs with a Winograd-packed weight copy run wino_x3.hpp: 0 off, 1 (default) F(2,3) (mcg_conv_weights.wf),
                                // 2 F(4,3) where the layer's shape allows it and the weights carry that copy (wf4), F(2,3) elsewhere: 6 % faster on
                                // the 56-wide maps for four times the operator error -- opt-in
@@ -203,6 +204,7 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "pointwise_pair")) e->pw_pair = value != 0;
   else if (!strcmp(name, "pointwise_stream")) e->pw_single = value != 0;
   else if (!strcmp(name, "bottleneck_fused")) e->bneck_fused = value != 0;
+  else if (!strcmp(name, "bottleneck_blocked")) e->bneck_blocked = value != 0;
   else if (!strcmp(name, "winograd")) { MCG_CHECK_ARG(value >= 0 && value <= 2, "winograd must be 0, 1 or 2"); e->winograd = value; }
   else if (!strcmp(name, "range_audit")) {
     MCG_CHECK_ARG(e->dt != MCG_BF16 || !value, "range_audit: f32-storage engines only (MCG_F32, MCG_F16X3)");
@@ -409,6 +411,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
   audit_tensor(au, "stem", t.x0, (long long)n * (H / 4) * (W / 4) * 64);
   const void* x = t.x0;
   int h = H / 4, w = W / 4, ci = 0;
+  bool x_blocked = false;  // x is in the fused tail's blocked layout (written by the previous block's fused tail for the next one's only)
   bool o1_ready = false;   // o1 already holds this block's conv1 output (written by the previous block's pointwise-pair / fused-tail kernel)
   char *o1 = t.o1, *o2 = t.o2;   // conv1 / conv2 outputs; the fused tail writes the NEXT conv1 output into o2 and the two swap
   for (int l = 0; l < 4; ++l) {
@@ -424,20 +427,39 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
       }
       o1_ready = false;
       // f16x3: conv2 -> conv3 (+ downsample / + residual) -> the next block's conv1 as ONE kernel (bneck_x3.hpp)
-      const mcg_fused_block* fb = nullptr;
-      if (dt == MCG_F16X3 && e->bneck_fused && e->ctx.tile < 0)
-        for (const mcg_fused_block& f : e->fused)
-          if (f.conv2_index == ci + 1) fb = &f;
+      // fused_at(conv index of a block's conv1, block index): that block's fused tail if one was handed over and every shape matches
+      auto fused_at = [&](int cj, int bj) -> const mcg_fused_block* {
+        if (!(dt == MCG_F16X3 && e->bneck_fused && e->ctx.tile < 0) || cj + 2 >= (int)e->convs.size()) return nullptr;
+        const mcg_fused_block* f = nullptr;
+        for (const mcg_fused_block& q : e->fused)
+          if (q.conv2_index == cj + 1) f = &q;
+        if (!f) return nullptr;
+        const bool ds = bj == 0;
+        const mcg_conv_weights &d2 = e->convs[cj + 1], &d3 = e->convs[cj + 2];
+        const int kk = ds ? e->convs[cj + 3].cin : 0, ss = ds ? e->convs[cj + 3].stride : 1;
+        const int cn_i = cj + (ds ? 4 : 3);
+        const bool nx = f->cn == 0 || (cn_i < (int)e->convs.size() && e->convs[cn_i].k == 1 && e->convs[cn_i].stride == 1 && e->convs[cn_i].cout == f->cn && e->convs[cn_i].cin == f->c);
+        return (d2.k == 3 && d2.stride == 1 && d2.pad == 1 && d2.cin == f->cm && d2.cout == f->cm && d3.cout == f->c && f->nsrc == (ds ? 2 : 1) && nx &&
+                bneck_x3_applicable(f->cm, f->c, f->cn, f->nsrc, kk, ss)) ? f : nullptr;
+      };
+      const mcg_fused_block* fb = fused_at(ci, b);
+      if (x_blocked && !(fb && fb->nsrc == 1)) { mcg_set_error("trunk: a blocked tensor reached a kernel that does not read that layout"); return MCG_ERR_UNSUPPORTED; }
       if (fb) {
-        const int k2 = has_ds ? e->convs[ci + 3].cin : 0, s2 = has_ds ? e->convs[ci + 3].stride : 1;
+        const int k2 = has_ds ? e->convs[ci + 3].cin : 0;
         const int ci_nx = ci + (has_ds ? 4 : 3);
-        const bool nx_ok = fb->cn == 0 || (ci_nx < (int)e->convs.size() && e->convs[ci_nx].k == 1 && e->convs[ci_nx].stride == 1 && e->convs[ci_nx].cout == fb->cn && e->convs[ci_nx].cin == fb->c);
-        if (c2.k == 3 && c2.stride == 1 && c2.pad == 1 && c2.cin == fb->cm && c2.cout == fb->cm && c3.cout == fb->c && fb->nsrc == (has_ds ? 2 : 1) && nx_ok &&
-            bneck_x3_applicable(fb->cm, fb->c, fb->cn, fb->nsrc, k2, s2)) {
+        {
           BneckParams bp;
           memset(&bp, 0, sizeof(bp));
           bp.x = (const float*)o1; bp.res = (const float*)x; bp.wstream = (const char*)fb->wstream; bp.bias = fb->bias;
           bp.y = (float*)y; bp.z = (float*)o2; bp.H = h; bp.W = w;
+          // y goes to the NEXT block's fused tail only (as its residual; its conv1 is this kernel's z, cn > 0): both sides use the kernel's blocked
+          // layout -- whole-line stores and loads (bneck_x3.hpp) -- where the block grid fits the ping-pong buffer; not under range_audit,
+          // which reads tensors as [M][C]
+          const long long blk_bytes = (long long)n * ((h + bnx::TH - 1) / bnx::TH) * ((w + bnx::TW - 1) / bnx::TW) * bnx::NPIX * fb->c * (long long)es;
+          const mcg_fused_block* fnext = (b + 1 < e->blocks[l]) ? fused_at(ci_nx, b + 1) : nullptr;
+          bp.res_blocked = x_blocked ? 1 : 0;
+          bp.y_blocked = (e->bneck_blocked && !e->audit_dev && y != (void*)t.c[l] && fb->cn > 0 && fnext && fnext->nsrc == 1 && fnext->c == fb->c &&
+                          blk_bytes <= (long long)((size_t)n * (H / 4) * (W / 4) * 256 * es)) ? 1 : 0;
           const double M = (double)n * h * w;
           ProfRec* rec = prof_begin(e->ctx, s, 70, n * h * w, fb->c + fb->cn, 9 * fb->cm + fb->cm + k2 + fb->c,
                                     2.0 * M * (9.0 * fb->cm * fb->cm + (double)(fb->cm + k2) * fb->c + (double)fb->c * fb->cn),
@@ -453,6 +475,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
           }
           if (fb->cn > 0) { char* tmp = o1; o1 = o2; o2 = tmp; o1_ready = true; }
           x = y; h = ho; w = wo;
+          x_blocked = bp.y_blocked != 0;
           ci = ci_nx;
           continue;
         }

@@ -233,7 +233,7 @@ class HipEngine:
 
     def set_option(self, name, value):
         """mcg_engine_set_option: 'trunk_streams', 'max_range_frames', 'tile', 'staged_gemm', 'conv3x3_c64', 'stem_fused',
-        'decoder_chain', 'pointwise_pair', 'pointwise_stream', 'bottleneck_fused', 'winograd', 'range_audit' (include/mcgaze_hip.h)."""
+        'decoder_chain', 'pointwise_pair', 'pointwise_stream', 'bottleneck_fused', 'bottleneck_blocked', 'winograd', 'range_audit' (include/mcgaze_hip.h)."""
         L.check(self.lib.mcg_engine_set_option(self._handle, name.encode(), int(value)), f'mcg_engine_set_option({name})')
 
     def range_audit(self, capacity=256):

@@ -512,6 +512,28 @@ def test_fused_bottleneck_tails_match_the_layer_granular_trunk(engines):
         e.set_option('bottleneck_fused', 1)
 
 
+def test_blocked_tensors_between_fused_tails_change_no_bit(engines):
+    """`bottleneck_blocked` (default 1): a tensor that only travels from one fused bottleneck tail to the next (the residual inside layer1 /
+    layer2) is stored in the kernel's blocked layout -- whole-line stores and loads.  A layout, not an arithmetic: pyramid and outputs must
+    be bit-identical to the engine with [M][C] tensors throughout, also where the 8 x 28 tiles do not tile the map (ragged: 96x160 gives
+    24x40 and 12x20 maps; 32x32 gives 8x8 and 4x4) and where the blocked grid would not fit its buffer (the engine then keeps [M][C])."""
+    e = engines['f16x3']
+    try:
+        for shape in ((3, 224, 224), (2, 96, 160), (5, 32, 32), (1, 448, 448), (4, 224, 256), (9, 64, 352)):
+            img = torch.from_numpy(synth.make_clips(67, 1, *shape)).to('cuda:0')
+            e.set_option('bottleneck_blocked', 0)
+            ref = [p.clone() for p in e.backbone_fpn(img)]
+            oref = {k: v.clone() for k, v in e.forward(img, shape[0]).items()}
+            e.set_option('bottleneck_blocked', 1)
+            out = e.backbone_fpn(img)
+            oout = e.forward(img, shape[0])
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(ref, out)), shape
+            assert all(torch.equal(oref[k], oout[k]) for k in oref), shape
+    finally:
+        e.set_option('bottleneck_blocked', 1)
+
+
 def test_pointwise_stream_kernel_is_bit_identical(engines):
     """pw_single.hpp (layer2's 1x1 convs and the P2 lateral as a persistent kernel with register-resident weights) against the
     generic contraction kernel: the pyramid must not change by a bit.  The kernel takes over from 64 Ki output pixels: 85 frames of
