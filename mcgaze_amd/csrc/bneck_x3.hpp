@@ -100,9 +100,12 @@ __device__ __forceinline__ void bnx_barrier_drained() {
   __builtin_amdgcn_s_barrier();
 }
 
-template <int CM, int NSRC, int CN>
+template <int CM, int NSRC, int CN, int LAYOUT>   // LAYOUT: bit 0 = the residual is blocked, bit 1 = y is blocked (BneckParams; compile-time: the
+                                                  // address forms as run-time values cost the CN = 128 instantiations 8 - 22 spilled registers)
 __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams p) {
   using namespace bnx;
+  constexpr bool RES_BLK = (LAYOUT & 1) != 0, Y_BLK = (LAYOUT & 2) != 0;
+  static_assert(!RES_BLK || NSRC == 1, "only a residual can arrive blocked");
   constexpr int C = 4 * CM, KH = CM / 64, NCH = C / 64;          // output channels, 64-channel K halves of conv2, 64-channel chunks of y
   constexpr int PARTS = CM / 64 + NSRC - 1;                      // 64-wide K parts of conv3 (t [| second source])
   constexpr int NS1 = 9 * KH * KH;                               // conv2 slabs: K half x tap x 64-channel output pair
@@ -247,10 +250,9 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
     // instruction touches 32 rows, 32 bytes of each (the two lane halves adjacent).  BLOCKED: per (tile, pixel group) a block of 32 x C floats ordered
     // [oc][c][q][pixel][half][4], so the 64 lanes of one instruction write ONE contiguous KiB -- eight whole lines instead of 32 quarter lines.
     // Measured on the layer1 identity block: a CU moves 11.5 B/clk with the quarter-line pattern, 18.5 with whole lines.
-    const long long blk = ((long long)tile * NG + g) * (32 * C) + pl * 8 + 4 * half;
-    const long long rbase = p.res_blocked ? blk : row * C + 4 * half, ybase = p.y_blocked ? blk : row * C + 4 * half;
-    const int r_so = p.res_blocked ? 2048 : 64, r_sc = p.res_blocked ? 1024 : 32, r_sq = p.res_blocked ? 256 : 8;
-    const int y_so = p.y_blocked ? 2048 : 64, y_sc = p.y_blocked ? 1024 : 32, y_sq = p.y_blocked ? 256 : 8;
+    // (wave-uniform block base + a per-lane constant: no vector registers per tile)
+    const long long sblk = ((long long)tile * NG + g) * (32 * C);
+    const uint32_t lane_off = (uint32_t)(pl * 8 + 4 * half);
     const int next = tile + stride;
     const bool has_next = next < p.total_tiles;
 
@@ -263,7 +265,9 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          rres[SL][c][q] = ld_ok ? *(const float4*)(p.res + rbase + chunk * r_so + c * r_sc + q * r_sq) : make_float4(0.f, 0.f, 0.f, 0.f);
+          rres[SL][c][q] = !ld_ok ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                  : (RES_BLK ? *(const float4*)(p.res + sblk + lane_off + chunk * 2048 + c * 1024 + q * 256)
+                                                   : *(const float4*)(p.res + row * C + chunk * 64 + c * 32 + 8 * q + 4 * half));
     };
     if constexpr (NSRC == 1) {
       static_for<RD>([&](auto d) { res_load(d, decltype(d)::value); });
@@ -380,7 +384,10 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
           float4 o = make_float4(acc2[c][4 * q] * ws3 + b.x, acc2[c][4 * q + 1] * ws3 + b.y, acc2[c][4 * q + 2] * ws3 + b.z, acc2[c][4 * q + 3] * ws3 + b.w);
           if constexpr (NSRC == 1) { const float4 r = rres[SLOT][c][q]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
           o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-          if (st_ok) *(float4*)(p.y + ybase + oc * y_so + c * y_sc + q * y_sq) = o;
+          if (st_ok) {
+            if constexpr (Y_BLK) *(float4*)(p.y + sblk + lane_off + oc * 2048 + c * 1024 + q * 256) = o;
+            else *(float4*)(p.y + row * C + ch) = o;
+          }
           acc2[c][4 * q] = o.x; acc2[c][4 * q + 1] = o.y; acc2[c][4 * q + 2] = o.z; acc2[c][4 * q + 3] = o.w;
         }
       if constexpr (NSRC == 1) {
@@ -439,7 +446,7 @@ static inline size_t bneck_x3_stream_bytes(int cm, int nsrc, int cn) {
   return (size_t)(9 * (cm / 64) * (cm / 64) + (cm / 16) * (cm / 64 + nsrc - 1 + cn / 64)) * bnx::SLAB;
 }
 
-template <int CM, int NSRC, int CN>
+template <int CM, int NSRC, int CN, int LAYOUT>
 static inline int launch_bneck_x3_t(hipStream_t s, const BneckParams& p) {
   constexpr int kLds = bnx::WIN_BYTES + bnx::RING_BYTES + (CM + 4 * CM + CN + 4) * 4;
   static int cus_of[MCG_MAX_DEVICES] = {0};
@@ -447,12 +454,17 @@ static inline int launch_bneck_x3_t(hipStream_t s, const BneckParams& p) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
   if (!cus_of[dev]) {
     hipDeviceProp_t prop;
-    if (hipFuncSetAttribute((const void*)bneck_x3_kernel<CM, NSRC, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)bneck_x3_kernel<CM, NSRC, CN, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return 1;
     cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
   const int grid = p.total_tiles < cus_of[dev] ? p.total_tiles : cus_of[dev];
-  hipLaunchKernelGGL((bneck_x3_kernel<CM, NSRC, CN>), dim3(grid), dim3(bnx::NT), kLds, s, p);
+  hipLaunchKernelGGL((bneck_x3_kernel<CM, NSRC, CN, LAYOUT>), dim3(grid), dim3(bnx::NT), kLds, s, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+// Which tensors may be blocked: y only where the next block's conv1 is this kernel's z on the same grid (cn = cm: a block inside a layer), the
+// residual only for nsrc = 1.  Anything else is refused (1) rather than run in the wrong layout.
+static inline bool bneck_x3_layout_ok(int cm, int nsrc, int cn, int res_blocked, int y_blocked) {
+  return (!res_blocked || nsrc == 1) && (!y_blocked || (cn == cm));
 }
 // frames x H x W pixels; returns 0 on success
 static inline int launch_bneck_x3(hipStream_t s, BneckParams p, int frames, int cm, int nsrc, int cn) {
@@ -462,13 +474,28 @@ static inline int launch_bneck_x3(hipStream_t s, BneckParams p, int frames, int 
   const long long total = (long long)p.tiles_per_frame * frames;
   if (total <= 0 || total > 0x7fffffffLL) return 1;
   p.total_tiles = (int)total;
-  if (cm == 128) return cn == 0 ? launch_bneck_x3_t<128, 1, 0>(s, p) : launch_bneck_x3_t<128, 1, 128>(s, p);
-  if (nsrc == 1) {
-    if (cn == 0) return launch_bneck_x3_t<64, 1, 0>(s, p);
-    if (cn == 64) return launch_bneck_x3_t<64, 1, 64>(s, p);
-    return launch_bneck_x3_t<64, 1, 128>(s, p);
+  if (!bneck_x3_layout_ok(cm, nsrc, cn, p.res_blocked, p.y_blocked)) return 1;
+  const int lay = (p.res_blocked ? 1 : 0) | (p.y_blocked ? 2 : 0);
+  if (cm == 128) {
+    if (cn == 0) return lay ? launch_bneck_x3_t<128, 1, 0, 1>(s, p) : launch_bneck_x3_t<128, 1, 0, 0>(s, p);
+    switch (lay) {
+      case 0: return launch_bneck_x3_t<128, 1, 128, 0>(s, p);
+      case 1: return launch_bneck_x3_t<128, 1, 128, 1>(s, p);
+      case 2: return launch_bneck_x3_t<128, 1, 128, 2>(s, p);
+      default: return launch_bneck_x3_t<128, 1, 128, 3>(s, p);
+    }
   }
-  if (cn == 0) return launch_bneck_x3_t<64, 2, 0>(s, p);
-  if (cn == 64) return launch_bneck_x3_t<64, 2, 64>(s, p);
-  return launch_bneck_x3_t<64, 2, 128>(s, p);
+  if (nsrc == 1) {
+    if (cn == 0) return lay ? launch_bneck_x3_t<64, 1, 0, 1>(s, p) : launch_bneck_x3_t<64, 1, 0, 0>(s, p);
+    if (cn == 128) return lay ? launch_bneck_x3_t<64, 1, 128, 1>(s, p) : launch_bneck_x3_t<64, 1, 128, 0>(s, p);
+    switch (lay) {
+      case 0: return launch_bneck_x3_t<64, 1, 64, 0>(s, p);
+      case 1: return launch_bneck_x3_t<64, 1, 64, 1>(s, p);
+      case 2: return launch_bneck_x3_t<64, 1, 64, 2>(s, p);
+      default: return launch_bneck_x3_t<64, 1, 64, 3>(s, p);
+    }
+  }
+  if (cn == 0) return launch_bneck_x3_t<64, 2, 0, 0>(s, p);
+  if (cn == 64) return lay ? launch_bneck_x3_t<64, 2, 64, 2>(s, p) : launch_bneck_x3_t<64, 2, 64, 0>(s, p);
+  return launch_bneck_x3_t<64, 2, 128, 0>(s, p);
 }
