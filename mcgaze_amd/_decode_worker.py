@@ -1,5 +1,5 @@
-"""Decode worker of pipeline.FrameCache(processes=True).  Started as a plain child process (`python _decode_worker.py <ring file> <slot
-bytes> <control file> <k> <n> <records per queue> <slots>`, not through multiprocessing: no fork of a process that holds a HIP context, no
+"""Decode worker of pipeline.FrameCache(processes=True).  Started as a plain child process (`python _decode_worker.py <ring fd> <slot
+bytes> <control fd> <k> <n> <records per queue> <slots>`, the two files being unlinked /dev/shm files inherited as descriptors, not through multiprocessing: no fork of a process that holds a HIP context, no
 re-import of the caller's main module, and this file imports neither torch, numpy nor the package).  It serves queue ``k`` of the
 mailbox pipeline._DecodeProcs lays out in the control file: a request record names a ring slot and a path; the file is decoded with
 PIL, its RGB uint8 pixels go into the memory-mapped ring file (/dev/shm) at that slot, then h, w and LAST the state word of the slot
@@ -18,13 +18,11 @@ REC = 1024                             # pipeline._DecodeProcs.REC
 
 def main():
     from PIL import Image              # no numpy here: its import alone is 0.2 s of start-up per helper; PIL hands out the pixel bytes itself
-    ring_path, slot_bytes, ctl_path, k, n, R, slots = sys.argv[1], int(sys.argv[2]), sys.argv[3], *map(int, sys.argv[4:8])
-    fd = os.open(ring_path, os.O_RDWR)
-    ring = mmap.mmap(fd, 0)
-    os.close(fd)
-    fd = os.open(ctl_path, os.O_RDWR)
-    ctl = mmap.mmap(fd, 0)
-    os.close(fd)
+    ring_fd, slot_bytes, ctl_fd, k, n, R, slots = map(int, sys.argv[1:8])
+    ring = mmap.mmap(ring_fd, 0)
+    os.close(ring_fd)
+    ctl = mmap.mmap(ctl_fd, 0)
+    os.close(ctl_fd)
     req_base = (64 + n * 128 + 4095) // 4096 * 4096
     stat_base = req_base + n * R * REC
     head_off, tail_off = 64 + k * 128, 64 + k * 128 + 64

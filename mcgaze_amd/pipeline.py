@@ -82,8 +82,9 @@ class _DecodeProcs:
 
     REC = 1024                                                   # bytes per request record: int64 slot, int32 path length, path
 
-    def __init__(self, n, ring_path, slot_bytes, slots, ring):
+    def __init__(self, n, ring_fd, slot_bytes, slots, ring, shm_dir=None):
         import mmap
+        import tempfile
         import subprocess
         import sys
         self.n, self.slots, self.ring, self.slot_bytes = int(n), int(slots), ring, int(slot_bytes)
@@ -91,17 +92,19 @@ class _DecodeProcs:
         self.req_base = (64 + self.n * 128 + 4095) // 4096 * 4096
         self.stat_base = self.req_base + self.n * self.R * self.REC
         size = self.stat_base + self.slots * 16
-        self.path = ring_path + '.ctl'
-        fd = os.open(self.path, os.O_RDWR | os.O_CREAT | os.O_EXCL, 0o600)
+        fd, path = tempfile.mkstemp(prefix='mcg_ctl_', dir=shm_dir)
+        os.unlink(path)
         os.ftruncate(fd, size)                                   # sparse: only the records in use ever get pages
         self.map = mmap.mmap(fd, size)
-        os.close(fd)
         self.stat = np.frombuffer(self.map, dtype=np.int32, count=self.slots * 4, offset=self.stat_base).reshape(self.slots, 4)
         self.tails = np.frombuffer(self.map, dtype=np.int64, count=self.n * 16, offset=64).reshape(self.n, 16)[:, 8]
         self.heads = np.zeros(self.n, dtype=np.int64)
         worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_decode_worker.py')
-        self.procs = [subprocess.Popen([sys.executable, worker, ring_path, str(slot_bytes), self.path, str(k), str(self.n), str(self.R), str(self.slots)],
-                                       stdin=subprocess.DEVNULL) for k in range(self.n)]
+        try:
+            self.procs = [subprocess.Popen([sys.executable, worker, str(ring_fd), str(slot_bytes), str(fd), str(k), str(self.n), str(self.R), str(self.slots)],
+                                           stdin=subprocess.DEVNULL, pass_fds=(ring_fd, fd)) for k in range(self.n)]
+        finally:
+            os.close(fd)
 
     def submit(self, path, slot):
         """Queue ``path`` for decoding into ring slot ``slot``.  False: the path does not fit a record (the caller decodes in line)."""
@@ -139,10 +142,6 @@ class _DecodeProcs:
                 p.kill()
         self.stat = self.tails = self.ring = None
         self.map = None
-        try:
-            os.unlink(self.path)
-        except OSError:
-            pass
 
 
 class FrameCache:
@@ -165,20 +164,26 @@ class FrameCache:
         self.rgb = loader is None                   # our own decode keeps the decoder's RGB order (DevicePipeline.run_many swaps in the kernel)
         self.loader = loader or (lambda path: LoadImageFromFile.load(path, rgb=True))
         self.capacity = max(int(capacity), 1)
-        self.ring, self.ring_path, self.procs, self.free, self.slot_bytes = None, None, None, [], int(slot_bytes)
+        self.ring, self._map, self.procs, self.free, self.slot_bytes = None, None, None, [], int(slot_bytes)
         self.pool = None
         if workers > 0 and processes:
             if loader is not None:
                 raise ValueError('FrameCache(processes=True) decodes with its own worker (PIL, RGB)')
             import tempfile
-            fd, self.ring_path = tempfile.mkstemp(prefix='mcg_ring_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+            # both shared files are ANONYMOUS: created in /dev/shm, unlinked at once, handed to the helpers as inherited descriptors -- nothing
+            # is left behind there however this process ends
+            shm = '/dev/shm' if os.path.isdir('/dev/shm') else None
+            fd, path = tempfile.mkstemp(prefix='mcg_ring_', dir=shm)
+            os.unlink(path)
             import mmap
-            os.ftruncate(fd, (self.capacity + 1) * self.slot_bytes)
-            self._map = mmap.mmap(fd, (self.capacity + 1) * self.slot_bytes)
-            os.close(fd)
-            self.ring = np.frombuffer(self._map, dtype=np.uint8)   # a plain ndarray: np.memmap's subclass machinery cost 5 us per slice
-            self.free = list(range(self.capacity + 1))
-            self.procs = _DecodeProcs(int(workers), self.ring_path, self.slot_bytes, self.capacity + 1, self.ring)
+            try:
+                os.ftruncate(fd, (self.capacity + 1) * self.slot_bytes)           # sparse: a slot gets pages when a frame is written into it
+                self._map = mmap.mmap(fd, (self.capacity + 1) * self.slot_bytes)
+                self.ring = np.frombuffer(self._map, dtype=np.uint8)   # a plain ndarray: np.memmap's subclass machinery cost 5 us per slice
+                self.free = list(range(self.capacity + 1))
+                self.procs = _DecodeProcs(int(workers), fd, self.slot_bytes, self.capacity + 1, self.ring, shm)
+            finally:
+                os.close(fd)
         elif workers > 0:
             self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix='mcg-decode')
         self.items = collections.OrderedDict()      # path -> Future (threads) / ring slot (processes) / array (in line), least recently used first
@@ -280,14 +285,8 @@ class FrameCache:
             self.procs = None
         self.items.clear()
         self.used.clear()
-        if self.ring_path is not None:
-            self.ring = None                                     # (views handed out earlier keep the mapping alive; it goes with the last of them)
-            self._map = None
-            try:
-                os.unlink(self.ring_path)
-            except OSError:
-                pass
-            self.ring_path = None
+        self.ring = None                                         # (views handed out earlier keep the mapping alive; it goes with the last of them)
+        self._map = None
 
 
 @PIPELINES.register_module()
