@@ -266,6 +266,26 @@ def test_f16x3_small_weights(eng, wscale):
         assert err_raw > 2 * err, (wscale, err, err_raw)    # measured in round 3: 1e-3 -> 4e-6
 
 
+@pytest.mark.parametrize('xscale', [1e2, 1.0, 1e-1])
+def test_f16x3_activation_magnitudes(eng, xscale):
+    """The ACTIVATION side of the same question (tools/act_scale_probe.py).  An activation below 0.125 has its fp16 low half in the subnormal
+    range -- an ABSOLUTE error of 2^-25, harmless while the tensor as a whole is O(0.1) or larger (every trunk tensor of both synthetic
+    weight families: per-layer median |x| 0.17 .. 8.5), not harmless for a tensor that is small as a whole: measured 3.3e-6 of
+    scale at |x| ~ 1e-2, 4e-5 at 1e-3 (the f32 kernel: 5e-7 throughout).  Activations are not pre-scaled (a per-tensor scale would make a
+    clip's bits depend on the batch it came in); the 22-bit product is asserted for tensors of magnitude 0.1 .. 100."""
+    g = torch.Generator().manual_seed(98)
+    N, H, W, Cin, Cout = 2, 12, 12, 256, 256
+    x = torch.randn(N, Cin, H, W, generator=g).relu() * xscale
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / 16
+    ref = F.conv2d(x.double(), w.double())
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to('cuda:0')
+    y = eng.conv2d(nhwc(x), nhwc(w), None, split=True)
+    torch.cuda.synchronize()
+    err = scale_err(y.permute(0, 3, 1, 2), ref.float())
+    print(f'f16x3 1x1 conv, activations ~{xscale:g}: {err:.2e} of scale')
+    assert err < 8e-7, (xscale, err)
+
+
 def test_conv2d_f16x3_randomized_shapes(eng):
     """The randomized sweep of test_conv2d_randomized_shapes for the f16x3 kernel (channel counts are multiples of 32: its K tile)."""
     rs = np.random.RandomState(4048)
