@@ -690,7 +690,7 @@ extern "C" size_t mcg_conv3x3_wino_x3_weight_bytes(int Cin, int Cout, int g) {
 extern "C" int mcg_conv3x3_wino_x3(mcg_stream s, const float* x, const void* u, const float* bias, float* y, int frames, int H, int W,
                                    int Cin, int Cout, int relu, int tile, float wscale, int g) {
   MCG_CHECK_ARG(x && u && y, "mcg_conv3x3_wino_x3: null pointer");
-  MCG_CHECK_ARG(tile >= 0 && tile <= 3, "mcg_conv3x3_wino_x3: tile must be 0 (by grid size) .. 3");
+  MCG_CHECK_ARG(tile >= 0 && tile <= 4, "mcg_conv3x3_wino_x3: tile must be 0 (by grid size) .. 4");
   if (!wino_x3_applicable(frames, H, W, Cin, Cout, g)) {
     mcg_set_error("mcg_conv3x3_wino_x3: unsupported shape (frames=%d %dx%d, %d -> %d channels, F(%d,3)): Cin %% 32, Cout %% 128, W <= 62 (F(4,3): W %% 4 == 0, W >= 16), a tile's window within its buffer", frames, H, W, Cin, Cout, g);
     return MCG_ERR_UNSUPPORTED;

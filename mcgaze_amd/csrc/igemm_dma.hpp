@@ -76,10 +76,21 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 // Two f32 -> their fp16 HIGH parts and fp16 LOW parts, packed: hi = RTZ_f16(x), lo = RTZ_f16(x - hi).  x - hi is exact, so hi + lo = x
 // to 2^-21 relative (22 significant bits) for |x| in [6e-5 * 2^11, 65504]; below that the low part is a subnormal half (absolute error
 // <= 6e-8), above it the halves saturate at +-65504 each (round toward zero never produces an infinity from a finite value).
+// Four VALU per pair: v_cvt_pkrtz, two v_fma_mix_f32 (x + (-1) * f32(half): the mixed-precision FMA reads the packed half directly, no
+// v_cvt_f32_f16 in front of a v_sub), v_cvt_pkrtz.  The -1 goes through an opaque scalar: written as a literal, the compiler folds the FMA
+// back into a subtraction of a converted value (six VALU per pair).  Same bits either way -- the difference is exact -- and the split is the
+// one piece of VALU work every f16x3 kernel does per activation element; on a chip that runs this path on its power cap
+// instructions are energy.
+__device__ __forceinline__ float mcg_opaque_m1() {
+  float m = -1.0f;
+  asm("" : "+s"(m));
+  return m;
+}
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& h, uint32_t& l) {
   const f16x2_t hh = __builtin_amdgcn_cvt_pkrtz(a, b);
   h = __builtin_bit_cast(uint32_t, hh);
-  l = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a - (float)hh[0], b - (float)hh[1]));
+  const float m1 = mcg_opaque_m1();
+  l = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)hh[0], m1, a), __builtin_fmaf((float)hh[1], m1, b)));
 }
 // one 32x32x16 product term of the split contraction (operands travel as 16-byte vectors; they hold eight halves)
 __device__ __forceinline__ f32x16 x3_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {

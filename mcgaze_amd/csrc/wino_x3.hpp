@@ -371,10 +371,301 @@ __global__ __launch_bounds__(64 * (G + 2) * RH, 1) void wino_x3_kernel(const Win
   }
 }
 
-// Tile shapes.  G = 2: 0 = 128 pairs x 128 channels (8 waves), 1 = 64 x 64 (8 waves), 2 = 32 x 64 (4 waves).  G = 4: 0 = 64 groups x 128
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the 128-pair x 128-channel F(2,3) tile with ONE WAVE PER SIMD.  The 8-wave kernel above is bound by what
+// two lock-stepped in-order waves per SIMD can issue: every wave issues its share of a K step's 32 KiB weight stage and of the window, reads
+// the weight fragments back from LDS, and all eight meet at a barrier every step.  Here a workgroup is four waves, wave nu = transform
+// position nu for ALL four row tiles of the tile (4 x 4 MFMA tiles = 256 accumulators: the accumulator half of the SIMD's 512-entry
+// register file), and
+//   * the WEIGHT fragments of position nu have exactly one reader -- this wave -- so they never touch LDS: eight 1 KiB buffer loads per K
+//     step straight into registers (the packed operand is fragment-major already), double-buffered by step parity, issued one step ahead;
+//     no ds_read of B, no barrier for B, half the LDS-DMA issue;
+//   * the WINDOW slice (shared by the four positions) stays in LDS, double-buffered; ONE barrier per 16-channel slice (three K steps)
+//     instead of one per step; a slice's pieces are issued two to three steps before the barrier that publishes them;
+//   * LDS holds only the two window buffers (96 KiB) in the K loop; the epilogue's staging (two passes of 64 pairs x 128 channels x 4
+//     positions = 128 KiB) overlays them.
+// Per accumulator the arithmetic is the 8-wave kernel's -- K steps in the same order, lo.hi, hi.lo, hi.hi per step, the same output
+// transform -- so the two kernels give the same bits (test_conv3x3_wino_x3_tiles_are_bit_identical covers shape 3 = this kernel).
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+template <int IMM>
+__device__ __forceinline__ void buf_load16(u32x4v& dst, uint32_t voffset, const u32x4& srd, uint32_t soffset_uniform) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=&v"(dst) : "v"(voffset), "s"(srd), "s"(soffset_uniform), "n"(IMM) : "memory");
+}
+template <int NB>
+__global__ __launch_bounds__(256, 1) void wino_x3w_kernel(const WinoParams p) {
+  using namespace wnx;
+  constexpr int G = 2, NV = 4, NW = 4, RT = 4, CT = 4, MT = 128, NT = 128;
+  constexpr int ROWB = NB * 1024, WIN_CAP = 48 * 1024, USTAGE = ustage(2);
+  constexpr int MAXP = WIN_CAP / 1024 / NW;            // window pieces per wave and slice (upper bound): 12, issued as two batches of 6
+  constexpr int HB = MAXP / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const s_win = smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nu = wave;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = logical / p.n_tiles, ntile = logical - mt * p.n_tiles;
+  int q0, q_end;
+  if (p.tpf > 0) {
+    const int f = mt / p.tpf, t = mt - f * p.tpf;
+    q0 = f * p.gpf + t * MT;
+    q_end = min(q0 + MT, (f + 1) * p.gpf);
+  } else {
+    q0 = mt * MT;
+    q_end = min(q0 + MT, p.total_pairs);
+  }
+  const int q_last = q_end - 1;
+  const int H1 = p.H + 1;
+  auto slot_of = [&](int q) { const int R = q / p.PW; return R + R / p.H + 1; };
+  const int sig_b = __builtin_amdgcn_readfirstlane(slot_of(q0) - 1);
+  const int NP = __builtin_amdgcn_readfirstlane((slot_of(q_last) - sig_b + 2) * NB);
+  const int NSL = p.Cin / KS, KT = 3 * NSL;
+  const int n0 = ntile * NT;
+  const u32x4 srd_x = make_srd(p.x);
+  const u32x4 srd_u = make_srd((const char*)p.u + (size_t)(n0 / UNT) * KT * USTAGE);
+  const uint32_t lds_win = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)s_win;
+
+  // ---- window pieces of this wave: piece pi = wave + 4 n = block pi % NB (= wave % NB for every n: NB divides 4) of window row pi / NB
+  uint32_t prow[MAXP];
+  uint32_t pokm = 0, prowokm = 0;
+  static_for<MAXP>([&](auto nc) {
+    constexpr int n = decltype(nc)::value;
+    const int pi = wave + NW * n, j = pi / NB;
+    const int sg = sig_b + j, f = sg / H1, r = sg - f * H1;
+    if (pi < NP) pokm |= 1u << n;
+    if (r != 0 && f < p.frames) prowokm |= 1u << n;
+    prow[n] = __builtin_amdgcn_readfirstlane((uint32_t)(((long long)(f * p.H + r - 1) * p.W) * p.Cin * 4));
+  });
+  pokm = __builtin_amdgcn_readfirstlane(pokm);
+  prowokm = __builtin_amdgcn_readfirstlane(prowokm);
+  uint32_t w_voff;
+  {
+    const int l_ph = lane >> 5, l_i = (lane >> 2) & 7, l_cs = lane & 3, b = wave & (NB - 1);
+    const int x = (8 * b + l_i) * G + l_ph - 1;
+    const int c = l_cs ^ ((2 * b + (l_i >> 2)) & 3);
+    w_voff = (unsigned)x < (unsigned)p.W ? (uint32_t)((x * p.Cin + 4 * c) * 4) : MCG_OOB_OFFSET;
+  }
+  auto issue_window = [&](auto hc, int cs, uint32_t dst) {       // batch hc (0, 1) of slice cs
+    constexpr int h0 = decltype(hc)::value * HB;
+    static_for<HB>([&](auto nc) {
+      constexpr int n = h0 + decltype(nc)::value;
+      if (pokm & (1u << n)) {
+        const uint32_t v = (prowokm & (1u << n)) ? w_voff : MCG_OOB_OFFSET;
+        lds_dma16<0>(v, srd_x, prow[n] + (uint32_t)cs * (KS * 4), dst + (uint32_t)(wave + NW * n) * 1024u);
+      }
+    });
+  };
+  // ---- weights of position nu: K step k = 8 KiB [channel tile][high, low][lane][16 B] at k USTAGE + nu 8192 of this channel block
+  const uint32_t b_voff = (uint32_t)lane * 16u + (uint32_t)nu * 8192u;
+  u32x4v bh[2][CT], bl[2][CT];
+  auto issue_b1 = [&](auto slc, auto jc, uint32_t koff) {        // one of the eight loads of a step: j = 2 ct + (0 high, 1 low)
+    constexpr int SLX = decltype(slc)::value, J = decltype(jc)::value;
+    if constexpr (J & 1) buf_load16<(J & 3) * 1024>(bl[SLX][J >> 1], b_voff, srd_u, koff + (J >> 2) * 4096u);
+    else buf_load16<(J & 3) * 1024>(bh[SLX][J >> 1], b_voff, srd_u, koff + (J >> 2) * 4096u);
+  };
+
+  // ---- input transform of this wave's position: V = d[toff0] + sgn d[toff1]
+  const int toff0 = nu == 0 ? 0 : 1, toff1 = nu == 3 ? 3 : 2;
+  const float tsg = nu == 1 ? 1.f : -1.f;
+  const int pl = lane & 31, h = lane >> 5;
+  const char* ap[RT][2][2];                               // window buffer 0, tap ky = 0
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int q = min(q0 + rt * 32 + pl, q_last);
+    const int R = q / p.PW, xg = q - R * p.PW;
+    const int jrow = (R + R / p.H + 1) - sig_b - 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int wx = G * xg + (t == 0 ? toff0 : toff1);
+      const int pp = wx / G, ph = wx - pp * G, swz = (pp >> 2) & 3;
+      const int off = jrow * ROWB + (pp >> 3) * (G * 512) + ph * 512 + (pp & 7) * 64;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) ap[rt][t][ch] = s_win + off + (((2 * h + ch) ^ swz) << 4);
+    }
+  }
+
+  f32x16 acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  struct Raw { uint4 d[RT][2][2]; };
+  auto load_raw = [&](auto wbc, auto kyc, Raw& r) {
+    constexpr int AOFF = decltype(wbc)::value * WIN_CAP + decltype(kyc)::value * ROWB;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { r.d[rt][t][0] = *(const uint4*)(ap[rt][t][0] + AOFF); r.d[rt][t][1] = *(const uint4*)(ap[rt][t][1] + AOFF); }
+  };
+  auto transform = [&](const Raw& r, bf16x8 (&ah)[RT], bf16x8 (&al)[RT]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t e0[4] = {r.d[rt][0][c].x, r.d[rt][0][c].y, r.d[rt][0][c].z, r.d[rt][0][c].w};
+        const uint32_t e1[4] = {r.d[rt][1][c].x, r.d[rt][1][c].y, r.d[rt][1][c].z, r.d[rt][1][c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * c + e] = fmaf(tsg, __uint_as_float(e1[e]), __uint_as_float(e0[e]));
+      }
+      const uint4 v0 = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+      const uint4 v1 = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+      split_f32x8(v0, v1, ah[rt], al[rt]);
+    }
+  };
+
+  // ---- prologue: slice 0 (both batches), the weights of step 0, the first batch of slice 1
+  issue_window(std::integral_constant<int, 0>{}, 0, lds_win);
+  issue_window(std::integral_constant<int, 1>{}, 0, lds_win);
+  static_for<8>([&](auto jc) { issue_b1(std::integral_constant<int, 0>{}, jc, 0u); });
+  if (NSL > 1) issue_window(std::integral_constant<int, 0>{}, 1, lds_win + WIN_CAP);
+  bf16x8 fh[2][RT], fl[2][RT];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    Raw r0;
+    load_raw(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, r0);
+    transform(r0, fh[0], fl[0]);
+  }
+  constexpr int NM1 = RT * CT;
+  uint32_t nh[RT][4], nl[RT][4];                          // the next step's A fragments while they are being made
+#pragma nounroll
+  for (int s2 = 0; s2 < NSL / 2; ++s2) {
+    static_for<6>([&](auto uc) {
+      constexpr int U = decltype(uc)::value, KY = U % 3, SL = U & 1, WB = U / 3;
+      constexpr int U1 = (U + 1) % 6, KY1 = U1 % 3, WB1 = U1 / 3;
+      const int k = 6 * s2 + U, cs = 2 * s2 + WB;
+      // this step's weights (issued one step ago) have landed -- and with them every window piece issued before them
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(bh[SL][0]), "+v"(bh[SL][1]), "+v"(bh[SL][2]), "+v"(bh[SL][3]), "+v"(bl[SL][0]), "+v"(bl[SL][1]), "+v"(bl[SL][2]), "+v"(bl[SL][3])
+                   :
+                   : "memory");
+      if constexpr (KY == 2) __builtin_amdgcn_s_barrier();   // slice cs + 1 is complete in its buffer; nobody reads slice cs's buffer any more
+      Raw raw;
+      load_raw(std::integral_constant<int, WB1>{}, std::integral_constant<int, KY1>{}, raw);
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t kn = (uint32_t)min(k + 1, KT - 1) * USTAGE;
+      // The step's vector-memory instructions -- the eight weight loads of the next step, then (ky = 2: first batch of slice cs + 2 into the
+      // buffer just released; ky = 0: second batch of slice cs + 1) six window pieces -- are issued ONE PER THREE OR FOUR MFMAs: the CU's address
+      // unit takes ~16 cycles per 1 KiB request and the four waves run the same stream, so requests behind consecutive MFMAs (32 cycles apart)
+      // queue up four deep and every wave stalls in its issue while its matrix pipe drains (measured: 70 cycles per weight load, 150 per
+      // window piece).  Three MFMAs apart, the waves fall into a rotation after the first collision and the issue hides under the MFMAs.
+      auto vmem_slot = [&](auto vc) {
+        constexpr int V = decltype(vc)::value;
+        if constexpr (V < 8) {
+          issue_b1(std::integral_constant<int, SL ^ 1>{}, std::integral_constant<int, V>{}, kn);
+        } else if constexpr (KY != 1 && V < 8 + HB) {
+          constexpr int n = (KY == 0 ? HB : 0) + (V - 8);
+          const int csn = KY == 0 ? cs + 1 : cs + 2;
+          if (csn < NSL && (pokm & (1u << n))) {
+            const uint32_t v = (prowokm & (1u << n)) ? w_voff : MCG_OOB_OFFSET;
+            lds_dma16<0>(v, srd_x, prow[n] + (uint32_t)csn * (KS * 4), lds_win + (KY == 0 ? (WB ^ 1) : WB) * WIN_CAP + (uint32_t)(wave + NW * n) * 1024u);
+          }
+        }
+      };
+      // term 1 (activation low x weight high): 16 MFMAs, a memory instruction behind MFMAs 0, 3, 6, 9, 12, 15
+      static_for<NM1>([&](auto mc) {
+        constexpr int M = decltype(mc)::value, I = M / CT, J = M % CT;
+        acc[I][J] = x3_mfma(fl[SL][I], __builtin_bit_cast(bf16x8, bh[SL][J]), acc[I][J]);
+        if constexpr (M % 3 == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          vmem_slot(std::integral_constant<int, M / 3>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      // terms 2 and 3: eight units of four MFMAs + a sixteenth of the next step's transform + split (16 VALU), a memory instruction behind each
+      static_for<8>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value, I = Q & 3, TERM3 = Q >> 2;
+        constexpr int XR = Q >> 1, XC = Q & 1;               // transform unit: row tile XR, 16-byte chunk XC of the next step's A fragment
+        {
+          const uint32_t e0[4] = {raw.d[XR][0][XC].x, raw.d[XR][0][XC].y, raw.d[XR][0][XC].z, raw.d[XR][0][XC].w};
+          const uint32_t e1[4] = {raw.d[XR][1][XC].x, raw.d[XR][1][XC].y, raw.d[XR][1][XC].z, raw.d[XR][1][XC].w};
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(tsg, __uint_as_float(e1[e]), __uint_as_float(e0[e]));
+          split_pair(v[0], v[1], nh[XR][2 * XC], nl[XR][2 * XC]);
+          split_pair(v[2], v[3], nh[XR][2 * XC + 1], nl[XR][2 * XC + 1]);
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < CT; ++j2)
+          acc[I][j2] = x3_mfma(fh[SL][I], __builtin_bit_cast(bf16x8, TERM3 ? bh[SL][j2] : bl[SL][j2]), acc[I][j2]);
+        // (the unit's results are only read one step later: without this pin instruction selection sinks all of a step's transform
+        // behind its last MFMA, where nothing covers it)
+        asm volatile("" : "+v"(nh[XR][2 * XC]), "+v"(nh[XR][2 * XC + 1]), "+v"(nl[XR][2 * XC]), "+v"(nl[XR][2 * XC + 1]));
+        static_for<4>([&](auto) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        vmem_slot(std::integral_constant<int, 6 + Q>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        fh[SL ^ 1][rt] = __builtin_bit_cast(bf16x8, make_uint4(nh[rt][0], nh[rt][1], nh[rt][2], nh[rt][3]));
+        fl[SL ^ 1][rt] = __builtin_bit_cast(bf16x8, make_uint4(nl[rt][0], nl[rt][1], nl[rt][2], nl[rt][3]));
+      }
+    });
+  }
+  // (the last step's weight loads -- a re-fetch of its own stage, nobody reads them -- are still in flight: their registers stay tied to
+  // this wait, or the compiler hands them to the epilogue's address arithmetic and the late data lands on a pointer.  Seen as a memory
+  // fault under a second engine's load only, where a load takes long enough.)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+               : "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[0][2]), "+v"(bh[0][3]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[0][2]), "+v"(bl[0][3]),
+                 "+v"(bh[1][0]), "+v"(bh[1][1]), "+v"(bh[1][2]), "+v"(bh[1][3]), "+v"(bl[1][0]), "+v"(bl[1][1]), "+v"(bl[1][2]), "+v"(bl[1][3])
+               :
+               : "memory");
+  __syncthreads();
+
+  // ---- epilogue: the 8-wave kernel's, two passes of two row tiles
+  constexpr int PP = 64, CPR = NT / 4;
+  float* const C = (float*)smem;                           // [nu][PP pairs][NT]
+  const float wsc = p.wscale > 0.f ? p.wscale : 1.f;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          C[(nu * PP + rt * 32 + mfma32_row(r, lane)) * NT + ct * 32 + (lane & 31)] = acc[2 * pass + rt][ct][r];
+    __syncthreads();
+    for (int item = tid; item < PP * CPR; item += 256) {
+      const int prl = item / CPR, ch4 = (item - prl * CPR) * 4;
+      const int q = q0 + pass * PP + prl;
+      if (q >= q_end) continue;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bv = *(const float4*)(p.bias + n0 + ch4);
+      float4 m[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) m[v] = *(const float4*)(C + (v * PP + prl) * NT + ch4);
+      float4 y[2];
+      y[0] = make_float4(((m[0].x + m[1].x) + m[2].x) * wsc + bv.x, ((m[0].y + m[1].y) + m[2].y) * wsc + bv.y, ((m[0].z + m[1].z) + m[2].z) * wsc + bv.z, ((m[0].w + m[1].w) + m[2].w) * wsc + bv.w);
+      y[1] = make_float4(((m[1].x - m[2].x) - m[3].x) * wsc + bv.x, ((m[1].y - m[2].y) - m[3].y) * wsc + bv.y, ((m[1].z - m[2].z) - m[3].z) * wsc + bv.z, ((m[1].w - m[2].w) - m[3].w) * wsc + bv.w);
+      const int R = q / p.PW, xo = G * (q - R * p.PW);
+      float* yp = p.y + ((long long)R * p.W + xo) * p.Cout + n0 + ch4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (xo + j >= p.W) break;
+        float4 o = y[j];
+        if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *(float4*)(yp + (long long)j * p.Cout) = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Tile shapes.  G = 2: 0 = 128 pairs x 128 channels (8 waves), 1 = 64 x 64 (8 waves), 2 = 32 x 64 (4 waves), 3 = 128 x 128 with one wave per
+// SIMD (wino_x3w_kernel).  G = 4: 0 = 64 groups x 128
 // channels (12 waves), 1 or 2 = 32 x 64 (6 waves).
-static inline int wino_x3_tile_groups(int g, int shape) { return g == 2 ? (shape == 0 ? 128 : (shape == 1 ? 64 : 32)) : (shape == 0 ? 64 : 32); }
-static inline int wino_x3_tile_channels(int shape) { return shape == 0 ? 128 : 64; }
+static inline int wino_x3_tile_groups(int g, int shape) { return g == 2 ? ((shape == 0 || shape == 3) ? 128 : (shape == 1 ? 64 : 32)) : (shape == 0 ? 64 : 32); }
+static inline int wino_x3_tile_channels(int shape) { return (shape == 0 || shape == 3) ? 128 : 64; }
 // 1 KiB pieces per window row, and the largest window (rows) a tile of mt groups can need: its rows, the zero rows between frames (cross:
 // tiles run over frame boundaries), two halo rows
 static inline int wino_x3_pieces(int W, int g) { return (g * ((W + g - 1) / g) + 2 + 8 * g - 1) / (8 * g) * (g / 2); }
@@ -419,7 +710,21 @@ static inline int launch_wino_x3_t(hipStream_t s, const WinoParams& p, int grid)
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 template <int NB>
+static inline int launch_wino_x3w(hipStream_t s, const WinoParams& p, int grid) {
+  constexpr int kLds = 4 * 64 * 128 * 4;                 // epilogue staging (the K loop uses the first 96 KiB: two window buffers)
+  static bool raised[MCG_MAX_DEVICES] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
+  if (!raised[dev]) {
+    if (hipFuncSetAttribute((const void*)wino_x3w_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return 1;
+    raised[dev] = true;
+  }
+  hipLaunchKernelGGL((wino_x3w_kernel<NB>), dim3(grid), dim3(256), kLds, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+template <int NB>
 static inline int launch_wino_x3_nb(hipStream_t s, const WinoParams& p, int g, int shape, int grid) {
+  if (g == 2 && shape == 3) return launch_wino_x3w<NB>(s, p, grid);
   if (g == 4) return shape == 0 ? launch_wino_x3_t<NB, 2, 1, 4, 4>(s, p, grid) : launch_wino_x3_t<NB, 1, 1, 2, 4>(s, p, grid);
   if (shape == 0) return launch_wino_x3_t<NB, 2, 2, 4, 2>(s, p, grid);
   if (shape == 1) return launch_wino_x3_t<NB, 2, 1, 2, 2>(s, p, grid);
@@ -439,8 +744,8 @@ static inline int launch_wino_x3(hipStream_t s, WinoParams p, int shape = -1, in
     return mode == 2 ? p.frames * ((p.gpf + mt - 1) / mt) : (p.total_pairs + mt - 1) / mt;
   };
   auto grid_of = [&](int sh) { return mtiles(sh) * (p.Cout / wino_x3_tile_channels(sh)); };
-  if (shape < 0) shape = grid_of(0) >= kWinoMinGrid ? 0 : ((g == 2 && grid_of(1) >= kWinoMinGrid) ? 1 : 2);
-  if (g == 4 && shape == 1) shape = 2;
+  if (shape < 0) shape = grid_of(0) >= kWinoMinGrid ? (g == 2 ? 3 : 0) : ((g == 2 && grid_of(1) >= kWinoMinGrid) ? 1 : 2);
+  if (g == 4 && (shape == 1 || shape == 3)) shape = 2;
   p.n_tiles = p.Cout / wino_x3_tile_channels(shape);
   p.tpf = mode == 2 ? (p.gpf + wino_x3_tile_groups(g, shape) - 1) / wino_x3_tile_groups(g, shape) : 0;
   const int grid = grid_of(shape);

@@ -93,7 +93,8 @@ def conv2d(x, w, bias=None, stride=1, pad=0, relu=False, residual=None, residual
 
 def conv3x3_wino(x, w, bias=None, relu=False, tile=0, g=2):
     """3x3 / stride 1 / pad 1 conv by the 1-D Winograd F(2,3) kernel of the MCG_F16X3 engine (mcg_conv3x3_wino_x3, wino_x3.hpp):
-    x NHWC f32, w OHWI f32 [Cout,3,3,Cin] (packed here by packing.wino_pack), bias f32 -> NHWC f32.  tile: 0 = by grid size, 1..3 forced.
+    x NHWC f32, w OHWI f32 [Cout,3,3,Cin] (packed here by packing.wino_pack), bias f32 -> NHWC f32.  tile: 0 = by grid size, 1..4 forced
+    (4 = the one-wave-per-SIMD 128 x 128 tile).
     g = 4: the F(4,3) form of the same kernel (maps whose width is a multiple of 4, at least 16)."""
     _require_gpu()
     lib = L.load()

@@ -219,16 +219,17 @@ def test_conv3x3_wino_x3_is_batch_invariant(eng):
     assert torch.equal(y5[:3], y3)
 
 
-@pytest.mark.parametrize('shape', [(7, 14, 14, 256, 256), (3, 9, 11, 64, 128), (2, 28, 28, 32, 256)])
+@pytest.mark.parametrize('shape', [(7, 14, 14, 256, 256), (3, 9, 11, 64, 128), (2, 28, 28, 32, 256), (3, 56, 56, 64, 128), (5, 7, 7, 512, 128), (2, 13, 30, 32, 256)])
 def test_conv3x3_wino_x3_tiles_are_bit_identical(eng, shape):
-    """The three workgroup tiles of wino_x3.hpp (128 x 128, 64 x 64, 32 x 64) walk K in the same order and apply the same output transform:
-    same bits, so the tile the launcher picks from the grid size (i.e. from the batch) never shows in a result."""
+    """The workgroup tiles of wino_x3.hpp (128 x 128 on eight waves, 64 x 64, 32 x 64, and round 5's 128 x 128 with one wave per SIMD and
+    the weight fragments straight from global memory) walk K in the same order and apply the same output transform: same bits, so the tile
+    the launcher picks from the grid size (i.e. from the batch) never shows in a result."""
     N, H, W, Cin, Cout = shape
     g = torch.Generator().manual_seed(4300 + N)
     x = torch.randn(N, H, W, Cin, generator=g).to('cuda:0')
     w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5).to('cuda:0')
     b = torch.randn(Cout, generator=g).to('cuda:0')
-    ys = [eng.conv3x3_wino(x, w, b, relu=True, tile=t) for t in (1, 2, 3, 0)]
+    ys = [eng.conv3x3_wino(x, w, b, relu=True, tile=t) for t in (1, 2, 3, 4, 0)]
     torch.cuda.synchronize()
     for y in ys[1:]:
         assert torch.equal(ys[0], y)
