@@ -69,7 +69,7 @@ CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,
              72: 'pw_single_x3_kernel<16,0,256> (dynamic_layer)',
              50: 'igemm_dma_kernel<float,256,256,128,4,2,2,2,x3>', 51: 'igemm_dma_kernel<float,128,128,128,2,2,2,2,x3>', 52: 'igemm_dma_kernel<float,256,64,128,4,1,2,2,x3>',
              53: 'igemm_dma_kernel<float,128,128,128,4,2,4,1,x3>',
-             73: 'wino_x3_kernel (3x3 / stride 1 as 1-D Winograd F(2,3); FLOPs booked as the direct convolution)'}
+             73: 'wino_x3_kernel (3x3 / stride 1 as 1-D Winograd F(2,3); FLOPs booked as the direct convolution)'}   # the Winograd FAMILY: wino_x3w_kernel<NB> (one wave per SIMD; grids of >= 130 workgroups) and the small-grid tiles of wino_x3_kernel
 
 
 def parse():
@@ -397,8 +397,19 @@ def roofline_of(rec, precision):
                            'MI355X_MICROARCH.md); bytes per launch, averaged over the symbol\'s launches; L2-miss traffic incl. Infinity-Cache hits',
          'algorithmic_bytes': 'layer-granular: inputs and residual read once, output written once, weights once (mcg_engine_profile_stop)'}
     if precision == 'f16x3':
-        r['note'] = ('achieved = ALGORITHMIC FLOP/s; the f16x3 contraction issues three fp16 MFMAs per algorithmic product, so the matrix pipe runs at '
-                     f'{round(3 * achieved, 1)} TFLOP/s = {round(3 * achieved / peak, 4)} of the 16-bit MFMA peak')
+        # matrix-pipe FLOPs per algorithmic FLOP: three fp16 MFMAs per product; the Winograd F(2,3) family multiplies 6 instead of 9 times
+        # per output (x 2 / 3; F(4,3), engine option winograd = 2: x 1 / 2)
+        mult = 2.0 if dom == 73 else 3.0
+        r['mfma_per_algorithmic_flop'] = mult
+        r['note'] = (f'achieved = ALGORITHMIC FLOP/s (a 3x3 conv booked as the direct convolution); this symbol issues {mult:g} matrix-pipe FLOPs per algorithmic '
+                     f'FLOP (three fp16 MFMAs per product' + (', 6 instead of 9 products per output: 1-D Winograd F(2,3)' if dom == 73 else '') + '), so the matrix pipe runs at '
+                     f'{round(mult * achieved, 1)} TFLOP/s = {round(mult * achieved / peak, 4)} of the 16-bit MFMA peak.  The chip runs every launch class of this path on its '
+                     '1.4 kW package cap at 1.75 - 2.2 GHz (profiles/r05_a_power_map.md): a pure MFMA loop on random data reaches 0.64 - 0.74 of the nameplate peak there')
+    if r['traffic_over_algorithmic'] is not None and r['traffic_over_algorithmic'] < 0.95:
+        # PMC bytes below the algorithmic bytes: a calibration or bookkeeping error (round 4: dynamic_layer launches averaged into the
+        # pw_single_x3 symbol), not a kernel that moves less than it must -- not printed as a ratio
+        r['traffic_note'] = f"PMC traffic / algorithmic bytes = {r['traffic_over_algorithmic']} < 0.95: counter calibration or symbol bookkeeping is off; ratio withheld"
+        r['traffic_over_algorithmic'] = None
     if step_bytes:
         r['hbm_step'] = {'bytes': int(step_bytes), 'contraction_launches_covered': covered, 'of': len(rec), 'peak_GBps': PEAK_HBM_GBPS,
                          'algorithmic_bytes': int(algo_step), 'over_algorithmic': round(step_bytes / algo_step, 3) if algo_step else None,
@@ -746,8 +757,8 @@ def main():
     if world > 1 and a.strong_clips > 0 and a.global_clips == 0 and a.workload == 'full' and a.strong_clips % world == 0:
         Bs = a.strong_clips // world
         if Bs == B:
-            strong = {'global_clips': a.strong_clips, 'clips_per_gpu': Bs, 'value': head['value'], 'ms_per_step': head['ms_per_step'],
-                      'note': 'identical to the headline configuration at this N (512 / N = clips_per_gpu)'}
+            strong = {'global_clips': a.strong_clips, 'clips_per_gpu': Bs, 'value': head['value'], 'ms_per_step': head['ms_per_step'], 'scaling': 'strong',
+                      'note': 'identical to the headline configuration at this N (strong clips / N = clips_per_gpu): not timed a second time'}
         else:
             simg = torch.from_numpy(synth.make_clips(3 + rank, Bs, T, a.size, a.size)).to(dev)
             stl = Leg(a, a.precision, dev, world, rank, dist, simg, Bs, T, engine=leg.eng)
@@ -778,6 +789,17 @@ def main():
             'frac_of_bf16_mfma_peak': head['frac_of_bf16_mfma_peak'],
             'roofline': head['roofline'],
         }
+        pfp = os.path.join(ROOT, 'profiles', 'parity_fuzz.json')
+        if a.precision in ('f16x3', 'fp32') and os.path.exists(pfp) and not a.fake_engine:
+            # how far the 1e-3 on (yaw, pitch) holds beyond the bench clip: committed evidence (tools/parity_fuzz.py against the CPU oracle),
+            # quoted with the library build it was taken on -- not measured in this run
+            from mcgaze_amd import lib as _lib
+            pf = json.load(open(pfp))
+            if a.precision in pf:
+                line['parity_fuzz'] = {'n': pf[a.precision]['n'], 'within': pf[a.precision]['within'], 'worst_rad': pf[a.precision]['worst_rad'],
+                                       'build_id': pf.get('build_id'), 'build_matches': pf.get('build_id') == _lib.build_id(),
+                                       'source': 'profiles/parity_fuzz.json: tools/parity_fuzz.py (random shapes, clip lengths, weight seeds) vs the CPU oracle, tolerance 1e-3 rad; '
+                                                 'the inputs beyond it are pinned as tests (tests/test_gpu_forward.py::test_known_fuzz_exceptions_stay_what_they_are)'}
         if 'rccl_ranks_verified' in head:
             line['rccl_ranks_verified'] = head['rccl_ranks_verified']
             line['rccl_verified_how'] = verify_ring_neighbour.__doc__.split('->')[0].strip().replace('\n    ', ' ')

@@ -94,7 +94,7 @@ typedef struct {
   int flags;            /* MCG_FLAG_* */
   float wscale;         /* MCG_F16X3 only, 0 = 1: y = wscale * (x . w) + bias ...  A power of two: the caller packs w PRE-SCALED by 1 / wscale so that
                            max |w| sits in (2^13, 2^14] and every fp16 low half down to 2^-17 of the largest weight is a NORMAL number (22 significant
-                           bits for weights of any magnitude; unscaled, a weight of 1e-3 keeps 15).  mcgaze_amd/packing.py::split_pack(scaled=True). */
+                           bits for weights of any magnitude; unscaled, a weight of 1e-3 keeps 15).  mcgaze_amd/packing.py::pow2_prescale, then split_pack. */
 } mcg_conv_desc;
 int mcg_conv2d(mcg_stream s, mcg_dtype dt, const mcg_conv_desc* d);
 

@@ -101,7 +101,7 @@ class _DecodeProcs:
         self.heads = np.zeros(self.n, dtype=np.int64)
         worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_decode_worker.py')
         try:
-            self.procs = [subprocess.Popen([sys.executable, worker, str(ring_fd), str(slot_bytes), str(fd), str(k), str(self.n), str(self.R), str(self.slots)],
+            self.procs = [subprocess.Popen([sys.executable, '-I', worker, str(ring_fd), str(slot_bytes), str(fd), str(k), str(self.n), str(self.R), str(self.slots)],
                                            stdin=subprocess.DEVNULL, pass_fds=(ring_fd, fd)) for k in range(self.n)]
         finally:
             os.close(fd)
@@ -140,6 +140,7 @@ class _DecodeProcs:
                 p.wait(timeout=5)
             except Exception:
                 p.kill()
+                p.wait()                                         # reap it: no zombie behind a helper that had to be killed
         self.stat = self.tails = self.ring = None
         self.map = None
 
@@ -157,6 +158,12 @@ class FrameCache:
     module is not re-imported) that write the RGB pixels into a memory-mapped ring file in /dev/shm of ``capacity`` slots (``slot_bytes``
     each; a larger frame is decoded in line); the consumer gets numpy views of the ring (valid while the frame stays cached: run_many
     copies them into its pinned staging buffer at once).
+    A ring view is only as good as its slot: a frame handed out as a view is therefore PINNED -- never evicted -- until ``release()``
+    (run_many calls it once its staging copy is made); a call that needs more distinct frames at once than the cache has slots raises
+    instead of handing out a view whose slot a later decode overwrites.  A caller that uses the cache directly calls ``release()`` when it
+    is done with the views it holds.  ``processes=True`` needs (capacity + 1) * slot_bytes of /dev/shm at most (pages are touched as slots
+    are used); when the tmpfs cannot back that (a container's default /dev/shm is 64 MB), the cache falls back to decode THREADS with a
+    warning -- a tmpfs that runs out under a mapped write is a SIGBUS in a helper, not an exception.
     Only the DECODE is shared: crop draws, geometry and the pixel kernel still run per window, in the caller's order -- results do
     not depend on the cache, the worker count or the worker kind."""
 
@@ -173,6 +180,18 @@ class FrameCache:
             # both shared files are ANONYMOUS: created in /dev/shm, unlinked at once, handed to the helpers as inherited descriptors -- nothing
             # is left behind there however this process ends
             shm = '/dev/shm' if os.path.isdir('/dev/shm') else None
+            try:
+                vfs = os.statvfs(shm or tempfile.gettempdir())
+                fit = int(vfs.f_bavail * vfs.f_frsize * 0.8) // self.slot_bytes - 1     # slots the file system can back, with a margin
+            except OSError:
+                fit = self.capacity
+            if fit < self.capacity + 1:                          # (worst case: every slot touched in full; no half measures -- a ring smaller
+                import warnings                                  #  than one run_many call's frames would only move the failure)
+                warnings.warn(f'FrameCache: {shm or tempfile.gettempdir()} cannot back {self.capacity + 1} ring slots of {self.slot_bytes} bytes '
+                              f'(room for {max(fit, 0)}); decoding on {workers} threads instead of helper processes')
+                processes = False
+        if workers > 0 and processes:
+            import tempfile
             fd, path = tempfile.mkstemp(prefix='mcg_ring_', dir=shm)
             os.unlink(path)
             import mmap
@@ -188,6 +207,7 @@ class FrameCache:
             self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix='mcg-decode')
         self.items = collections.OrderedDict()      # path -> Future (threads) / ring slot (processes) / array (in line), least recently used first
         self.used = collections.OrderedDict()       # paths the consumer has already asked for, oldest use first: the eviction candidates
+        self.held = set()                           # paths handed out as ring views since the last release(): not evictable
         self.lock = threading.Lock()
         self.decodes = 0
         self.waits, self.wait_s, self.first_wait_s = 0, 0.0, 0.0            # times the consumer found a frame not decoded yet, and how long it then waited
@@ -223,12 +243,22 @@ class FrameCache:
         # A frame decoded AHEAD and not yet asked for is the one the consumer needs next: plain LRU threw exactly those out (they are the
         # oldest entries once the cache is full -- every prefetch then cost a second, synchronous decode: round 3's "threads are slower").
         # Victims are frames already consumed, oldest use first; an unconsumed one only when nothing else is left.
-        victim = None
+        victim, kept = None, []
         while self.used and victim is None:
             p, _ = self.used.popitem(last=False)
-            if p in self.items:
+            if p in self.held:
+                kept.append(p)                                   # its view is still out: not a candidate (back in line below)
+            elif p in self.items:
                 victim = p
-        old = self.items.pop(victim) if victim is not None else self.items.popitem(last=False)[1]
+        for p in reversed(kept):
+            self.used[p] = True
+            self.used.move_to_end(p, last=False)
+        if victim is None:
+            victim = next((p for p in self.items if p not in self.held), None)
+            if victim is None:
+                raise RuntimeError(f'FrameCache: all {len(self.items)} cached frames are handed out as views of the decode ring; raise capacity '
+                                   f'({self.capacity}) above the distinct frames of one run_many call, or release() between uses')
+        old = self.items.pop(victim)
         if isinstance(old, int):                                 # ring slot: its writer must be done before the slot is handed out again
             try:
                 self.procs.wait(old)
@@ -274,8 +304,13 @@ class FrameCache:
             if state == 2:
                 return self.loader(path)                         # larger than a slot: decoded here
             o = e * self.slot_bytes
+            self.held.add(path)                                  # a view of the ring: the slot stays until release()
             return self.ring[o:o + h * w * 3].reshape(h, w, 3)
         return self._wait(e) if isinstance(e, concurrent.futures.Future) else e
+
+    def release(self):
+        """The views handed out so far are no longer read (run_many: copied into the staging buffer): their slots may be evicted again."""
+        self.held.clear()
 
     def close(self):
         if self.pool is not None:
@@ -535,6 +570,8 @@ class DevicePipeline:
         dev = torch.device(device)
         if dev.type != 'cuda':
             raise L.McgError('DevicePipeline runs its pixel work on the GPU (mcg_preprocess_frames); there is no CPU path')
+        if dev.index is None:                                     # 'cuda': the current device, by index -- the staging buffers are compared with it
+            dev = torch.device('cuda', torch.cuda.current_device())
         rgb_source = all(isinstance(f, str) for w in windows for f in w)      # our own decode: keep PIL's RGB order, the kernel swaps
         if loader is not None:
             load = loader
@@ -596,6 +633,8 @@ class DevicePipeline:
             host_np = host.numpy()
             for a, o in zip(arrays, offs):
                 host_np[int(o):int(o) + a.size] = a.reshape(-1)
+            if hasattr(loader, 'release'):
+                loader.release()                                  # ring views of a FrameCache: copied, their slots may go
             # descriptors (mcg_frame_desc), built as one structured array per padded size
             src_a = np.asarray(src, dtype=np.int64)
             shp = np.asarray([a.shape[:2] for a in arrays], dtype=np.int32)

@@ -1,5 +1,6 @@
 """world_size-2 gloo test of the only multi-GPU exchange on the path (mcgaze_amd/dist.py)."""
 import os
+import pytest
 import socket
 
 import torch
@@ -125,26 +126,29 @@ def test_dataset_run_shards_videos_and_gathers_records_in_annotation_order():
 
 
 # ------------------------------------------------------------------------------------ bench.py's N > 1 branch, executed
-def test_bench_world2_control_flow_with_the_fake_engine():
-    """bench.main() under `torch.distributed.run --nproc-per-node 2` (the driver's launch line) with the host stand-in
-    engine and gloo -- clip sharding by rank, the fused exchange, verify_ring_neighbour's rank_views branch, the strong-scaling leg and
-    the stdout hand-over all execute here before an 8-GPU node ever runs them.  The numbers are meaningless; the SHAPE of the line is
-    what is asserted: one JSON line, last on stdout, world_size 2, both ranks' neighbour checks passed, strong_scaling present."""
+@pytest.mark.parametrize('world', [2, 4])
+def test_bench_control_flow_with_the_fake_engine(world):
+    """bench.main() under `torch.distributed.run --nproc-per-node N` (the driver's launch line) with the host
+    stand-in engine and gloo -- clip sharding by rank, the fused exchange, verify_ring_neighbour's rank_views branch, the strong-scaling leg
+    and the stdout hand-over all execute here before an 8-GPU node ever runs them; N = 4 so that an off-by-one in the ring neighbour
+    ((r + 1) % N) or in rank_views cannot hide behind N = 2, where the neighbour is simply "the other one".  The numbers are meaningless; the
+    SHAPE of the line is what is asserted: one JSON line, last on stdout, world_size N, every rank's neighbour check passed, strong_scaling
+    present with the fixed batch divided by N."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--fake-engine', '--steps', '3', '--warmup', '1',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', str(world), '--fake-engine', '--steps', '3', '--warmup', '1',
            '--clips-per-gpu', '2', '--size', '32', '--strong-clips', '8']
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     line = json.loads(lines[-1])                                   # nothing after the JSON line
     assert sum(1 for ln in lines if ln.lstrip().startswith('{"metric"')) == 1
-    assert line['n_gpus'] == 2 and line['world_size'] == 2 and line['scaling'] == 'weak'
-    assert line['rccl_ranks_verified'] == 2                        # every rank matched its ring neighbour's block bit for bit
+    assert line['n_gpus'] == world and line['world_size'] == world and line['scaling'] == 'weak'
+    assert line['rccl_ranks_verified'] == world                    # every rank matched its ring neighbour's block bit for bit
     assert line['verified'] is True
     st = line['strong_scaling']
-    assert st['global_clips'] == 8 and st['clips_per_gpu'] == 4 and st['scaling'] == 'strong' and st['value'] > 0
-    assert line['config']['global_clips'] == 4 and 'FAKE ENGINE' in line['data']
+    assert st['global_clips'] == 8 and st['clips_per_gpu'] == 8 // world and st['scaling'] == 'strong' and st['value'] > 0
+    assert line['config']['global_clips'] == 2 * world and 'FAKE ENGINE' in line['data']

@@ -554,6 +554,53 @@ def test_pointwise_stream_kernel_is_bit_identical(engines):
         e.set_option('pointwise_stream', 1)
 
 
+# The three inputs of the 2 400-case fuzz (tools/parity_fuzz.py, seeds 2 / 7 / 11) on which the f16x3 engine leaves 1e-3 rad on (yaw, pitch),
+# pinned by name: what IS true of them is asserted, so a build that makes them worse fails here and not only in a
+# 20-minute fuzz run.  (fuzz seed, case, kind, bound on the angle between the engine's and the oracle's gaze vectors)
+KNOWN_FUZZ_EXCEPTIONS = [
+    (7, 502, 'pole', 4e-5),        # oracle gaze y = +0.9999: yaw = atan2(x, -z) amplifies a 3e-5 rad vector error to 1.0e-3 on the yaw
+    (11, 279, 'pole', 4e-5),       # oracle gaze y = +0.9996: 1.08e-3 on the yaw from a 3.1e-5 rad vector error
+    (11, 721, 'validity', 5e-3),   # one RoIAlign sample on the other side of its validity edge (box 1e-3 px from the oracle's): 4.5e-3 rad
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed,case,kind,bound', KNOWN_FUZZ_EXCEPTIONS)
+def test_known_fuzz_exceptions_stay_what_they_are(seed, case, kind, bound):
+    """profiles/r04_r_parity_fuzz_final.md: 2 397 of 2 400 random inputs within 1e-3 rad.  The two pole inputs must keep their gaze VECTOR
+    within 4e-5 rad of the oracle's with no level / sample-validity flip anywhere in the chain (the 1e-3 on the yaw is the coordinate
+    singularity, not the arithmetic); the validity-edge input may cross its ONE discontinuity and must stay within 5e-3 rad.  The fp32
+    engine is inside 1e-3 on all three."""
+    from mcgaze_amd.engine import HipEngine
+    from tests import parity_tools as PT
+    k = synth.fuzz_case(seed, case)
+    sd = synth.make_state_dict(k['wseed'])
+    stages = []
+    _, ref = orc.forward(sd, k['img'], k['metas'], k['T'], collect=stages)
+    want = orc.yaw_pitch(ref['gaze_score'])
+    N = k['B'] * k['T']
+    hw = None if k['full'] else np.tile(np.array(k['img_shape'], dtype=np.int32), (N, 1))
+    for prec in ('f16x3', 'fp32'):
+        eng = HipEngine(sd, precision=prec)
+        out = eng.forward(torch.from_numpy(k['img']).cuda(), k['T'], img_hw=hw)
+        g = out['gaze'][0].cpu()
+        ang = float((2 * torch.asin(((g.double() - ref['gaze_score'].double()).norm(dim=-1) / 2).clamp(max=1))).max())
+        d = float(orc.wrap_yaw(orc.yaw_pitch(g) - want).abs().max())
+        print(f'fuzz seed {seed} case {case} ({kind}) {prec}: max d(yaw, pitch) {d:.3e} rad, max angle between gaze vectors {ang:.3e} rad')
+        if prec == 'fp32':
+            assert d <= 1e-3, (prec, d)
+            continue
+        assert ang <= bound, (prec, ang)
+        rep = PT.stage_report(eng, prec, sd, k['img'], k['metas'], k['T'], stages)
+        flips = sum(a + v for a, v, _, _ in rep['free_running'])
+        assert max(rep['teacher_forced']) < 1e-4, rep['teacher_forced']       # every stage, fed the oracle's inputs, is parity-grade
+        if kind == 'pole':
+            assert flips == 0 and d <= 2e-3, (flips, d)                           # no discontinuity; the yaw error is the pole's amplification
+            assert float(ref['gaze_score'][:, 1].abs().max()) > 0.999             # ... and the input IS a pole input
+        else:
+            assert flips <= 1 and d <= 5e-3, (flips, d)
+
+
 FUZZ_CASES = 16
 FUZZ_MAX_CROSSINGS = {'fp32': 0, 'f16x3': 1}   # asserted RATE over the 16 cases: profiles/r02_m_parity_fuzz.md measured 0 / 2400 (fp32) and 1 / 2400 (f16x3)
 FUZZ_CROSSED_CLIP_BOUND = 0.05                 # rad, gaze-vector angle inside a clip whose chain crossed a discontinuity (the one observed: 4.5e-3)

@@ -156,9 +156,38 @@ def test_frame_cache_helper_processes(tmp_path):
             for k in (0, 1, 2, 3, 4, 5, 6, 7, 2, 0):
                 got = cache(paths[k])
                 assert got.dtype == np.uint8 and got.shape == want[k].shape and np.array_equal(got, want[k]), k
+                cache.release()                                  # done with the view: its slot may be evicted again
         assert cache.decodes >= len(paths)
         with pytest.raises(RuntimeError, match='decode worker'):
             cache(str(tmp_path / 'absent.png'))
+    finally:
+        cache.close()
+
+
+def test_frame_cache_never_recycles_a_view_that_is_still_out(tmp_path):
+    """a ring view handed out by FrameCache(processes=True) stays valid until release() -- a later miss must not evict its slot
+    and let another frame's pixels show through the view.  More views out than the cache has slots raises instead of corrupting, and
+    DevicePipeline.run_many's contract (release once the staging copy is made) is what makes a small cache usable across calls."""
+    from PIL import Image
+    from mcgaze_amd.pipeline import FrameCache, LoadImageFromFile
+    rs = np.random.RandomState(5)
+    paths = []
+    for i in range(8):
+        paths.append(str(tmp_path / f'{i}.png'))
+        Image.fromarray(rs.randint(0, 256, (24, 20, 3)).astype(np.uint8)).save(paths[-1])
+    want = [LoadImageFromFile.load(p, rgb=True) for p in paths]
+    cache = FrameCache(workers=2, capacity=4, processes=True, slot_bytes=24 * 20 * 3)
+    try:
+        views = [cache(p) for p in paths[:4]]
+        with pytest.raises(RuntimeError, match='handed out as views'):
+            cache(paths[4])                                      # a fifth view needs a slot; every slot backs a view that is still out
+        for v, w in zip(views, want):
+            assert np.array_equal(v, w)                          # ... and the four that are out are untouched
+        cache.release()
+        for k in range(4, 8):                                    # after release the slots go round again
+            assert np.array_equal(cache(paths[k]), want[k])
+        cache.release()
+        assert np.array_equal(cache(paths[0]), want[0])
     finally:
         cache.close()
 

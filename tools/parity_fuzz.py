@@ -71,3 +71,20 @@ print()
 print('worst: ' + ', '.join(f'{p} {worst[p]:.3e} rad' for p in precs) + '  (north_star tolerance 1e-3)')
 for p in precs:
     print(f'{p}: ' + ', '.join(f'{k}: {v}' for k, v in sorted(counts[p].items())) + f' of {cases} cases')
+# machine-readable summary, merged over runs into gpurun_out/parity_fuzz.json (copy to profiles/parity_fuzz.json: bench.py quotes it as
+# `parity_fuzz` with the library build id it was taken on)
+import json
+from mcgaze_amd import lib as L
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = os.path.join(root, 'gpurun_out', 'parity_fuzz.json')
+os.makedirs(os.path.dirname(path), exist_ok=True)
+doc = json.load(open(path)) if os.path.exists(path) else {}
+if doc.get('build_id') != L.build_id() or doc.get('family') != family or doc.get('options') != [f'{n}={v}' for n, _, v in opts]:
+    doc = {'build_id': L.build_id(), 'family': family, 'options': [f'{n}={v}' for n, _, v in opts], 'runs': {}}
+doc['runs'][f'seed {seed}'] = {'cases': cases, 'engines': {p: {'within_1e-3': counts[p]['within 1e-3'], 'worst_rad': worst[p],
+                                                              'beyond': {k: v for k, v in counts[p].items() if k != 'within 1e-3'}} for p in precs},
+                               'exceptions': diag}
+for p in precs:
+    runs = [r for r in doc['runs'].values() if p in r['engines']]
+    doc[p] = {'n': sum(r['cases'] for r in runs), 'within': sum(r['engines'][p]['within_1e-3'] for r in runs), 'worst_rad': max(r['engines'][p]['worst_rad'] for r in runs)}
+json.dump(doc, open(path, 'w'), indent=1)

@@ -12,6 +12,7 @@ clips, overlaps are merged per video and results/results_<config>_<json> is writ
 --seed fixes the crop draws of CenterCrop(crop_type='relative_range'), which the reference leaves to the unseeded global RNG
 (SURVEY.md section 5)."""
 import argparse
+import zlib
 import json
 import os
 import sys
@@ -90,7 +91,7 @@ def main(argv=None):
     rng = np.random.RandomState(a.seed + rank) if a.seed is not None else None
     recs = harness.run_annotation(model.engine(), dict(videos=[anno['videos'][i] for i in idx]), a.root, pipe, batch_clips=a.batch_clips, rng=rng, workers=a.workers,
                                   processes=a.decode == 'processes',
-                                  video_rng=(lambda vid: np.random.RandomState(((a.seed or 0) * 1000003 + int(vid)) & 0x7fffffff)) if a.per_video_seed else None)
+                                  video_rng=(lambda vid: np.random.RandomState(((a.seed or 0) * 1000003 + zlib.crc32(str(vid).encode())) & 0x7fffffff)) if a.per_video_seed else None)
     torch.cuda.synchronize()
     t_run = time.time()
     if world > 1:
