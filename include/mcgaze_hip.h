@@ -115,7 +115,8 @@ int mcg_bottleneck_x3(mcg_stream s, const float* x, const float* src2, const voi
  * 2 <= W <= 62 and a 128-pair tile's input window (its rows + halo rows, 16 channels) within 48 KiB -- every level of a 224 x 224
  * input; MCG_ERR_UNSUPPORTED otherwise (use mcg_conv2d).  The result differs from mcg_conv2d's in rounding only (both within 1e-6 of
  * scale of the f64 convolution); it does not depend on how the frames are batched.  tile: 0 = chosen by grid size; 1 / 2 / 3 force the
- * 128 x 128 / 64 x 64 / 32 x 64 (pairs x channels) workgroup tile -- all three give the same bits.  wscale: as mcg_conv_desc.wscale (u packed
+ * 128 x 128 / 64 x 64 / 32 x 64 (pairs x channels) workgroup tile of the 8-wave kernel, 4 the 128 x 128 tile with one wave per SIMD and the
+ * weight fragments read straight from global memory (g = 2 only; what tile 0 picks for grids of >= 130 workgroups) -- all give the same bits.  wscale: as mcg_conv_desc.wscale (u packed
  * pre-scaled by its inverse; 0 = 1).  g: output pixels per transform group -- 2 = F(2,3) (the description above), 4 = F(4,3): six positions for
  * four outputs, 4.5 products per output; u = wino_pack(w, g=4) (24 / 9 of the OHWI tensor); additionally needs W % 4 == 0 and W >= 16; tile 1 = 64
  * groups x 128 channels, 2 / 3 = 32 x 64.  Its transform constants cost about 1.5 bits against the direct kernel (measured: tests). */
