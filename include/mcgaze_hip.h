@@ -148,7 +148,8 @@ int mcg_roi_align(mcg_stream s, mcg_dtype dt, const void* const feats[4], const 
  */
 enum {
   MCG_SW_IN_PROJ_W = 0, MCG_SW_IN_PROJ_B, MCG_SW_OUT_PROJ_W, MCG_SW_OUT_PROJ_B, MCG_SW_ATTN_LN_G, MCG_SW_ATTN_LN_B,
-  MCG_SW_DYN_W,      /* dynamic_layer.weight rows permuted so param_in comes out [64][256] and param_out [256][64] (K contiguous) */
+  MCG_SW_DYN_W,      /* dynamic_layer.weight rows permuted (mcgaze_amd/packing.py::dyn_permutation(epc = elements per 16-byte chunk)) so that a token's
+                        param_in^T [64][256] and param_out^T [256][64] come out in the MFMA-fragment-major order dynconv_kernel reads */
   MCG_SW_DYN_B,      /* permuted the same way, f32 */
   MCG_SW_NORM_IN_G, MCG_SW_NORM_IN_B, MCG_SW_NORM_OUT_G, MCG_SW_NORM_OUT_B,
   MCG_SW_FC_W, MCG_SW_FC_B, MCG_SW_FC_LN_G, MCG_SW_FC_LN_B, MCG_SW_IIC_LN_G, MCG_SW_IIC_LN_B,

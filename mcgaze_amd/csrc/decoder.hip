@@ -117,8 +117,8 @@ static LnParams ln_simple(const void* src, const float* g, const float* b, int r
 
 // ------------------------------------------------------------------------------------------------
 // DynamicConv core (transformer.py:1131-1148), one workgroup (4 waves) per token:
-//   F1 = ReLU(LN64 (F[49x256]  . Win[256x64]))     Win^T  = params[r][0     .. 16384) as [64][256]
-//   F2 = ReLU(LN256(F1[49x64]  . Wout[64x256]))    Wout^T = params[r][16384 .. 32768) as [256][64]
+//   F1 = ReLU(LN64 (F[49x256]  . Win[256x64]))     Win^T  = params[r][0     .. 16384): [64][256] in MFMA-fragment-major order
+//   F2 = ReLU(LN256(F1[49x64]  . Wout[64x256]))    Wout^T = params[r][16384 .. 32768): [256][64] likewise (packing.py::dyn_permutation)
 // The 49 positions are padded to 64 rows (2 MFMA row tiles).  MFMA operand fragments for F and
 // the generated weights are read straight from global/L2 (each is used by one token only);
 // F1 goes through LDS (f32 for the LayerNorm, then dtype, chunk-swizzled, as the next A operand).
@@ -150,10 +150,11 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const T* __restrict__ roi,
   // ---- stage 1: wave -> one 32x32 tile of D1[64][64]
   {
     const int tm = wave >> 1, tn = wave & 1;
-    const int prow = tm * 32 + (lane & 31), ncol = tn * 32 + (lane & 31);
+    const int prow = tm * 32 + (lane & 31);
     const bool pv = prow < P;
     const T* ap = F + (long long)prow * DI + (lane >> 5) * EPC;
-    const T* bp = Win + (long long)ncol * DI + (lane >> 5) * EPC;
+    // the generated weights arrive MFMA-fragment-major (packing.py::dyn_permutation): chunk pair j of column tile tn = one contiguous KiB
+    const T* bp = Win + ((long long)tn * (DI / (2 * EPC)) * 64 + lane) * EPC;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const T* __restrict__ roi,
 #pragma unroll
       for (int j = 0; j < GRP; ++j) {
         a[j] = pv ? *(const uint4*)(ap + (j0 + j) * 2 * EPC) : make_uint4(0, 0, 0, 0);
-        b[j] = *(const uint4*)(bp + (j0 + j) * 2 * EPC);
+        b[j] = *(const uint4*)(bp + (j0 + j) * 64 * EPC);
       }
 #pragma unroll
       for (int j = 0; j < GRP; ++j) Mma<T>::run(acc, a[j], b[j]);
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const T* __restrict__ roi,
 #pragma unroll
   for (int j = 0; j < PAIRS2; ++j)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) bf2[j][b] = *(const uint4*)(Wout + (long long)(wave * 64 + b * 32 + (lane & 31)) * DF + (2 * j + (lane >> 5)) * EPC);
+    for (int b = 0; b < 2; ++b) bf2[j][b] = *(const uint4*)(Wout + ((long long)((wave * 2 + b) * PAIRS2 + j) * 64 + lane) * EPC);
   __syncthreads();
   // ---- LN over 64 features + ReLU, one wave per row, lane = feature; write F1 as dtype A operand
   for (int row = wave; row < 64; row += 4) {
@@ -245,6 +246,159 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const T* __restrict__ roi,
     T* dst = out + ((long long)r * P + row) * DI + lane * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) Elem<T>::st(dst + e, fmaxf(v[e] * rstd * g_out[lane * 4 + e] + b_out[lane * 4 + e], 0.f));
+  }
+}
+
+// The same in the f16x3 arithmetic (MCG_F16X3 engine; round 5): f32 storage, both operands of both contractions split into fp16 high / low
+// parts, three v_mfma_f32_32x32x16_f16 per product (lo.hi + hi.lo + hi.hi, the contraction kernels' order) instead of f32 MFMAs at 1/16 of
+// the rate.  The generated weights arrive in THIS kernel's fragment order (packing.py::dyn_permutation(epc = 8): a lane's eight K elements of a
+// 32x32x16 step are 32 contiguous bytes, a wave's two loads 2 KiB) and are split in registers; F1 is split ONCE when the LayerNorm writes
+// it and parked in LDS as fp16 high / low planes (its four readers would each split it again).  Round 3 measured an x3 DynamicConv with
+// K-contiguous parameter rows (a load touched 32 rows x 32 bytes) as slower than the f32 kernel; with whole-KiB loads it is the faster one.
+__global__ __launch_bounds__(256) void dynconv_x3_kernel(const float* __restrict__ roi, const float* __restrict__ params,
+                                                         const float* __restrict__ g_in, const float* __restrict__ b_in,
+                                                         const float* __restrict__ g_out, const float* __restrict__ b_out,
+                                                         float* __restrict__ out) {
+  constexpr int P = 49, DI = 256, DF = 64;
+  constexpr int D1_LD = DF + 4, D2_LD = DI + 4;
+  constexpr int A2_ROWB = DF * 2;                          // bytes per F1 row of one fp16 plane
+  constexpr int A2_PLANE = 64 * A2_ROWB;                   // 8 KiB
+  constexpr int D1_BYTES = 64 * D1_LD * 4;
+  constexpr int D2_BYTES = P * D2_LD * 4;                  // D2 aliases D1 and the planes (barrier in between)
+  constexpr int LDS_BYTES = D2_BYTES > D1_BYTES + 2 * A2_PLANE ? D2_BYTES : D1_BYTES + 2 * A2_PLANE;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  float* D1 = (float*)smem;
+  float* D2 = (float*)smem;
+  char* A2h = smem + D1_BYTES;
+  char* A2l = A2h + A2_PLANE;
+
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const float* __restrict__ F = roi + (long long)r * P * DI;
+  const float* __restrict__ Win = params + (long long)r * (2 * DI * DF);
+  const float* __restrict__ Wout = Win + DI * DF;
+
+  // ---- stage 1: wave -> one 32x32 tile of D1[64][64], K = 256 = 16 steps
+  {
+    const int tm = wave >> 1, tn = wave & 1;
+    const int prow = tm * 32 + (lane & 31);
+    const bool pv = prow < P;
+    const float* ap = F + (long long)prow * DI + 8 * h;
+    const float* bp = Win + ((long long)tn * 16 * 64 + lane) * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    constexpr int GRP = 4;                                 // K steps whose operand fragments are in flight together
+#pragma unroll
+    for (int s0 = 0; s0 < 16; s0 += GRP) {
+      uint4 a[GRP][2], b[GRP][2];
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        a[j][0] = pv ? *(const uint4*)(ap + (s0 + j) * 16) : make_uint4(0, 0, 0, 0);
+        a[j][1] = pv ? *(const uint4*)(ap + (s0 + j) * 16 + 4) : make_uint4(0, 0, 0, 0);
+        b[j][0] = *(const uint4*)(bp + (s0 + j) * 512);
+        b[j][1] = *(const uint4*)(bp + (s0 + j) * 512 + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        bf16x8 ah, al, bh, bl;
+        split_f32x8(a[j][0], a[j][1], ah, al);
+        split_f32x8(b[j][0], b[j][1], bh, bl);
+        acc = x3_mfma(al, bh, acc);
+        acc = x3_mfma(ah, bl, acc);
+        acc = x3_mfma(ah, bh, acc);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) D1[(tm * 32 + mfma32_row(i, lane)) * D1_LD + tn * 32 + (lane & 31)] = acc[i];
+  }
+  // stage 2's weight fragments (wave -> columns [wave*64, +64) of Wout^T, K = 64 = 4 steps): issued now, consumed after the LayerNorm
+  uint4 bf2[4][2][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float* q = Wout + ((long long)((wave * 2 + b) * 4 + s) * 64 + lane) * 8;
+      bf2[s][b][0] = *(const uint4*)q;
+      bf2[s][b][1] = *(const uint4*)(q + 4);
+    }
+  __syncthreads();
+  // ---- LN over 64 features + ReLU, one wave per row, lane = feature; F1 split once into the fp16 planes (16-byte chunks XOR-swizzled
+  // by row pair: a fragment read's 16 lanes hit 16 distinct bank groups)
+  for (int row = wave; row < 64; row += 4) {
+    float v = D1[row * D1_LD + lane];
+    const float mean = wave_sum(v) * (1.0f / DF);
+    const float d = v - mean;
+    const float rstd = 1.0f / sqrtf(wave_sum(d * d) * (1.0f / DF) + 1e-5f);
+    v = fmaxf(d * rstd * g_in[lane] + b_in[lane], 0.f);
+    uint32_t hh, ll;
+    split_pair(v, 0.f, hh, ll);                            // (the packed pair's second half is not stored)
+    const int chunk = lane >> 3, within = lane & 7;
+    const int off = row * A2_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4) + within * 2;
+    *(uint16_t*)(A2h + off) = (uint16_t)(hh & 0xffffu);
+    *(uint16_t*)(A2l + off) = (uint16_t)(ll & 0xffffu);
+  }
+  __syncthreads();  // D1 fully consumed, the planes complete
+  // ---- stage 2: wave -> columns [wave*64, +64) of D2[64][256], 2x2 tiles, K = 64
+  {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ch = 2 * s + h;
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int row = a * 32 + (lane & 31);
+        const int off = row * A2_ROWB + ((ch ^ ((row >> 1) & 7)) << 4);
+        ah[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(A2h + off));
+        al[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(A2l + off));
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) split_f32x8(bf2[s][b][0], bf2[s][b][1], bh[b], bl[b]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = x3_mfma(al[a], bh[b], acc[a][b]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = x3_mfma(ah[a], bl[b], acc[a][b]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = x3_mfma(ah[a], bh[b], acc[a][b]);
+    }
+    __syncthreads();  // every wave is done reading the planes before D2 (which aliases them) is written
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = a * 32 + mfma32_row(i, lane);
+          if (row < P) D2[row * D2_LD + wave * 64 + b * 32 + (lane & 31)] = acc[a][b][i];
+        }
+  }
+  __syncthreads();
+  // ---- LN over 256 channels + ReLU, one wave per position, lane owns 4 consecutive channels
+  for (int row = wave; row < P; row += 4) {
+    const float4 t = *(const float4*)(D2 + row * D2_LD + lane * 4);
+    float v[4] = {t.x, t.y, t.z, t.w};
+    const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / DI);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / DI) + 1e-5f);
+    const float4 g = *(const float4*)(g_out + lane * 4), bb = *(const float4*)(b_out + lane * 4);
+    float4 o;
+    o.x = fmaxf(v[0] * rstd * g.x + bb.x, 0.f); o.y = fmaxf(v[1] * rstd * g.y + bb.y, 0.f);
+    o.z = fmaxf(v[2] * rstd * g.z + bb.z, 0.f); o.w = fmaxf(v[3] * rstd * g.w + bb.w, 0.f);
+    *(float4*)(out + ((long long)r * P + row) * DI + lane * 4) = o;
   }
 }
 
@@ -474,6 +628,7 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
     MCG_TRY(launch_linear(s, dt, w.x2, 256, W[MCG_SW_DYN_W], f32w[MCG_SW_DYN_B], nullptr, 0, w.params, 32768, R, 256, 32768, 0, ctx));
   }
   if (bf) hipLaunchKernelGGL(dynconv_kernel<bf16_t>, dim3(R), dim3(256), 0, s, (const bf16_t*)roi_feat, (const bf16_t*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (bf16_t*)w.feat2);
+  else if (dt == MCG_F16X3) hipLaunchKernelGGL(dynconv_x3_kernel, dim3(R), dim3(256), 0, s, (const float*)roi_feat, (const float*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (float*)w.feat2);
   else hipLaunchKernelGGL(dynconv_kernel<float>, dim3(R), dim3(256), 0, s, (const float*)roi_feat, (const float*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (float*)w.feat2);
   MCG_CHECK_LAUNCH("dynconv");
   int slabs = 1;

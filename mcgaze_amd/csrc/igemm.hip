@@ -17,10 +17,7 @@ void mcg_set_error(const char* fmt, ...) {
 }
 extern "C" const char* mcg_last_error(void) { return g_err; }
 extern "C" int mcg_abi_version(void) { return MCG_ABI_VERSION; }
-#ifndef MCG_BUILD_ID
-#define MCG_BUILD_ID "unknown"
-#endif
-extern "C" const char* mcg_build_id(void) { return MCG_BUILD_ID; }
+// (mcg_build_id lives in build_id.hip: the one object that is rebuilt whenever ANY kernel source or the public header changes)
 extern "C" int mcg_device_info(int* cu_count, size_t* hbm_bytes, char* arch, int arch_len) {
   int dev = 0;
   hipDeviceProp_t prop;

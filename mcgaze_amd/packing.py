@@ -8,7 +8,7 @@ buffers ``libmcgaze_hip.so`` expects (``include/mcgaze_hip.h``):
   (eval-mode BN, resnet.py:648-658), computed in float64;
 * conv weights OIHW -> OHWI (K = (kh, kw, cin) contiguous) in the compute dtype;
 * stem 7x7x3 -> [64][7][8][4] (kw and channel zero-padded: one kernel row is one 32-element tap);
-* ``dynamic_layer`` rows permuted so the generated 1x1-conv weights come out K-contiguous;
+* ``dynamic_layer`` rows permuted so the generated 1x1-conv weights come out in dynconv_kernel's MFMA-fragment-major read order;
 * per-clue heads and the gaze-head branches stacked into the tables the kernels index.
 """
 import numpy as np
@@ -172,13 +172,27 @@ def bneck_stream(w2, b2, w3, b3, w1n=None, b1n=None):
     return torch.stack(slabs).reshape(-1).contiguous(), bias.contiguous()
 
 
-def dyn_permutation(d=256, feat=64):
-    """Row permutation of dynamic_layer: new row n*d+k <- old row k*feat+n (param_in^T, [feat][d]);
-    new row d*feat + n*feat+k <- old row d*feat + k*d+n (param_out^T, [d][feat]); transformer.py:1134-1137."""
-    n, k = torch.meshgrid(torch.arange(feat), torch.arange(d), indexing='ij')
-    p_in = (k * feat + n).reshape(-1)
-    n2, k2 = torch.meshgrid(torch.arange(d), torch.arange(feat), indexing='ij')
-    p_out = (d * feat + k2 * d + n2).reshape(-1)
+def dyn_permutation(d=256, feat=64, epc=4):
+    """Row permutation of dynamic_layer (transformer.py:1134-1137: params[:, :d*feat].view(d, feat) = param_in, params[:, -d*feat:]
+    .view(feat, d) = param_out) so that a token's generated weights come out in the order dynconv_kernel READS them: MFMA-fragment-major,
+    one contiguous KiB per wave-wide 16-byte load (round 5; before: K-contiguous rows, where a load touched 32 rows x 32 bytes).
+    ``epc`` = K elements a lane holds per load group: 4 (fp32 engine: one 16-byte chunk), 8 (bf16: one chunk; f16x3: two chunks of f32 that
+    dynconv_x3_kernel splits into the eight halves of a 32x32x16 step).
+      stage 1, B operand = param_in^T [n < feat][k < d]: offset ((tn * (d / 2 epc) + j) * 64 + lane) * epc + e holds
+               n = 32 tn + (lane & 31), k = (2 j + (lane >> 5)) * epc + e                          <- old row k * feat + n
+      stage 2, B operand = param_out^T [n < d][k < feat], wave w = n / 64, b = (n / 32) & 1: offset d * feat +
+               (((2 w + b) * (feat / 2 epc) + j) * 64 + lane) * epc + e holds n = 64 w + 32 b + (lane & 31), k = (2 j + (lane >> 5)) * epc + e
+                                                                                                   <- old row d * feat + k * d + n"""
+    lane, e = torch.arange(64), torch.arange(epc)
+    def frag(tiles, pairs):   # -> n [tiles, pairs, 64, epc], k [tiles, pairs, 64, epc]
+        t, j = torch.arange(tiles), torch.arange(pairs)
+        n = (32 * t[:, None, None, None] + (lane & 31)[None, None, :, None]).expand(tiles, pairs, 64, epc)
+        k = ((2 * j[None, :, None, None] + (lane >> 5)[None, None, :, None]) * epc + e[None, None, None, :]).expand(tiles, pairs, 64, epc)
+        return n.reshape(-1), k.reshape(-1)
+    n, k = frag(feat // 32, d // (2 * epc))
+    p_in = k * feat + n
+    n2, k2 = frag(d // 32, feat // (2 * epc))
+    p_out = d * feat + k2 * d + n2
     return torch.cat([p_in, p_out])
 
 
@@ -278,7 +292,7 @@ class PackedWeights:
             self.fpn_out.append(entry(w, sd[f'neck.fpn_convs.{i}.conv.bias'], 3, 1, 1, wf=wf3x3, wf4=wf3x3_g4))
         self.init_boxes = vec(sd['rpn_head.init_proposal_bboxes.weight'])
         self.init_feats = self._dev(sd['rpn_head.init_proposal_features.weight'].to(dtype))   # read by a non-GEMM kernel: storage dtype
-        perm = dyn_permutation()
+        perm = dyn_permutation(epc=8 if (dtype == torch.bfloat16 or split) else 4)   # f16x3: dynconv_x3_kernel takes eight K elements per lane and step
         self.stages = []
         for s in range(num_stages):
             p = f'roi_head.bbox_head.{s}'

@@ -124,14 +124,28 @@ def test_library_exports_every_declared_symbol():
     assert sw == L.STAGE_KEYS and gw == L.GAZE_KEYS and L.SW_COUNT == 39 and L.GW_COUNT == 7
 
 
-def test_dyn_permutation_matches_reference_view():
-    """params[:, :d*f].view(d, f) / params[:, -d*f:].view(f, d) (transformer.py:1134-1137) -> K-contiguous rows."""
+@pytest.mark.parametrize('epc', [4, 8])
+def test_dyn_permutation_matches_reference_view(epc):
+    """params[:, :d*f].view(d, f) / params[:, -d*f:].view(f, d) (transformer.py:1134-1137) -> the MFMA-fragment-major order dynconv_kernel
+    reads (packing.dyn_permutation): every element of param_in^T [f][d] and param_out^T [d][f] sits where lane l of the wave-wide 16-byte
+    load of (tile, chunk pair j) expects it, and the permutation is a bijection."""
     from mcgaze_amd.packing import dyn_permutation
     d, f = 256, 64
     theta = torch.arange(2 * d * f, dtype=torch.float32)
     w_in, w_out = theta[:d * f].view(d, f), theta[-d * f:].view(f, d)
-    p = theta[dyn_permutation(d, f)]
-    assert torch.equal(p[:d * f].view(f, d), w_in.t()) and torch.equal(p[d * f:].view(d, f), w_out.t())
+    perm = dyn_permutation(d, f, epc)
+    assert sorted(perm.tolist()) == list(range(2 * d * f))
+    p = theta[perm]
+    win_t, wout_t = w_in.t(), w_out.t()                                # [f][d], [d][f]: B operands with K contiguous
+    pin = p[:d * f].view(f // 32, d // (2 * epc), 64, epc)
+    pout = p[d * f:].view(d // 32, f // (2 * epc), 64, epc)
+    for lane in (0, 5, 31, 32, 63):
+        for t, j in ((0, 0), (1, 3), (f // 32 - 1, d // (2 * epc) - 1)):
+            k0 = (2 * j + (lane >> 5)) * epc
+            assert torch.equal(pin[t, j, lane], win_t[32 * t + (lane & 31), k0:k0 + epc])
+        for t, j in ((0, 0), (5, 1), (d // 32 - 1, f // (2 * epc) - 1)):
+            k0 = (2 * j + (lane >> 5)) * epc
+            assert torch.equal(pout[t, j, lane], wout_t[32 * t + (lane & 31), k0:k0 + epc])
 
 
 def test_bn_fold_equals_conv_then_bn():
