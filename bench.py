@@ -102,6 +102,7 @@ def parse():
     ap.add_argument('--decoder-priority', type=int, default=-1, help='HIP stream priority of the batch pipeline\'s decoder stream (-1 = high: the default; 0 = the trunk\'s)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the cpu_baseline leg (rank 0, N=1 only); 0 disables')
     ap.add_argument('--latency', type=int, default=1, choices=[0, 1], help='1: report single-clip latency (rank 0, N=1 only)')
+    ap.add_argument('--power-seconds', type=float, default=1.5, help='N = 1: seconds of the product schedule sampled for package power / shader clock after the timed region (0 disables)')
     ap.add_argument('--host-input-steps', type=int, default=20, help='timed steps of the host_input leg (rank 0, N=1 only; 0 disables)')
     ap.add_argument('--engine-option', action='append', default=[], metavar='NAME=INT',
                     help='mcg_engine_set_option on every engine of the run (A/B of a kernel variant, e.g. winograd=2); recorded in config.engine_options')
@@ -341,6 +342,23 @@ class Leg:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed
+
+    def run_for(self, seconds):
+        """The product schedule for about `seconds` of wall time, outside any timed region (power_probe)."""
+        import contextlib
+        ctx = torch.cuda.stream(self.runner.sa) if self.runner is not None else contextlib.nullcontext()
+        n, t0 = 0, time.perf_counter()
+        with ctx:
+            while time.perf_counter() - t0 < seconds:
+                for _ in range(4):
+                    self.step()
+                n += 4
+                if n % 8 == 0:              # the host enqueues a step in under a millisecond: without this it would run half a minute ahead
+                    self.drain()
+                    _sync(self.dev)
+            self.drain()
+        _sync(self.dev)
+        return n, time.perf_counter() - t0
 
     def verify(self):
         """The timed schedule's last outputs (both pipeline slots) against the strictly serial schedule on the same batch: bitwise."""
@@ -623,6 +641,54 @@ def host_input_leg(eng, dev, B, T, size, steps, warmup=4):
     return out
 
 
+def power_probe(leg, seconds=1.5):
+    """Package power and shader clock WHILE the product schedule runs (rocm-smi sampled from a thread, in a loop of its own AFTER the timed
+    region, so the sampling cannot touch `value`).  The path runs on the package power cap (profiles/r05_a_power_map.md): a step takes its
+    energy divided by the cap, and the clock below the chip's maximum is the firmware trading frequency for power -- this object is that
+    statement measured in the same run as the headline."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    if shutil.which('rocm-smi') is None:
+        return None
+    dev_arg = ['-d', str(leg.dev.index or 0)]
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                t = subprocess.run(['rocm-smi'] + dev_arg + ['--showclocks', '--showpower'], capture_output=True, text=True, timeout=5).stdout
+            except Exception:
+                return
+            m = re.search(r'sclk clock level: \S+ \((\d+)Mhz\)', t)
+            pw = re.search(r'Power \(W\): ([\d.]+)', t)
+            if m and pw:
+                samples.append((int(m.group(1)), float(pw.group(1))))
+            time.sleep(0.1)
+    th = threading.Thread(target=poll, daemon=True)
+    leg.run_for(0.3)                        # clocks settled before the first sample
+    th.start()
+    n, el = leg.run_for(seconds)
+    stop.set()
+    th.join(timeout=10)
+    s = samples[1:-1] if len(samples) > 4 else samples
+    if not s:
+        return None
+    cap = None
+    try:
+        t = subprocess.run(['rocm-smi'] + dev_arg + ['--showmaxpower'], capture_output=True, text=True, timeout=5).stdout
+        m = re.search(r'Max Graphics Package Power \(W\): ([\d.]+)', t)
+        cap = float(m.group(1)) if m else None
+    except Exception:
+        pass
+    w = sum(x[1] for x in s) / len(s)
+    return {'package_power_W': round(w, 0), 'power_cap_W': cap, 'frac_of_cap': round(w / cap, 3) if cap else None,
+            'sclk_MHz': round(sum(x[0] for x in s) / len(s), 0), 'max_sclk_MHz': 2400, 'samples': len(s),
+            'ms_per_step_while_sampled': round(el / n * 1e3, 3), 'joules_per_step': round(w * el / n, 2),
+            'how': 'rocm-smi --showclocks --showpower every 0.1 s from a thread while the product schedule loops for ~1.5 s AFTER the timed region (not inside it)'}
+
+
 def timed_leg(leg, steps, warmup, total_per_step, flops_per_clip, world):
     el = leg.timed(steps, warmup)
     v = total_per_step * steps / el
@@ -653,6 +719,7 @@ def main():
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run for N > 1'
     if a.fake_engine:   # control-flow rehearsal on the host (tests/test_dist_cpu.py): no second engine, no GPU-only legs
         a.second_engine, a.kernel_events, a.backbone_clips, a.mae_videos, a.host_input_steps, a.latency, a.cpu_seconds = 'none', 'none', 0, 0, 0, 0, 0.0
+        a.power_seconds = 0.0
         a.exact_steps = 0
         dev = torch.device('cpu')
     else:
@@ -710,6 +777,8 @@ def main():
             gbps = roof['hbm_step']['bytes'] / (el / steps) / 1e9
             roof['hbm_step'].update({'achieved_GBps': round(gbps, 1), 'frac': round(gbps / PEAK_HBM_GBPS, 4)})
         res['roofline'] = roof
+        if world == 1 and a.power_seconds > 0 and a.workload == 'full':
+            res['power'] = power_probe(leg, a.power_seconds)
         back = None
         if world == 1 and a.backbone_clips > 0 and a.workload == 'full':
             del leg.runner
@@ -789,6 +858,8 @@ def main():
             'frac_of_bf16_mfma_peak': head['frac_of_bf16_mfma_peak'],
             'roofline': head['roofline'],
         }
+        if head.get('power'):
+            line['power'] = head['power']
         pfp = os.path.join(ROOT, 'profiles', 'parity_fuzz.json')
         if a.precision in ('f16x3', 'fp32') and os.path.exists(pfp) and not a.fake_engine:
             # how far the 1e-3 on (yaw, pitch) holds beyond the bench clip: committed evidence (tools/parity_fuzz.py against the CPU oracle),
