@@ -192,6 +192,35 @@ def test_frame_cache_never_recycles_a_view_that_is_still_out(tmp_path):
         cache.close()
 
 
+def test_frame_cache_falls_back_to_threads_when_shm_cannot_back_the_ring(tmp_path, monkeypatch):
+    """the decode ring is a sparse /dev/shm file; a tmpfs that runs out under a mapped write is a SIGBUS in a helper, not an
+    exception (a container's default /dev/shm is 64 MB).  FrameCache checks the free space against the ring's worst case and decodes on
+    threads, with a warning, when it does not fit -- same pixels, no helper processes."""
+    import os as _os
+    from PIL import Image
+    from mcgaze_amd import pipeline as P
+    rs = np.random.RandomState(9)
+    paths = []
+    for i in range(3):
+        paths.append(str(tmp_path / f'{i}.png'))
+        Image.fromarray(rs.randint(0, 256, (20, 16, 3)).astype(np.uint8)).save(paths[-1])
+    real = _os.statvfs
+
+    class Tiny:
+        def __init__(self, st):
+            self.f_frsize, self.f_bavail = st.f_frsize, (8 << 20) // st.f_frsize        # 8 MiB free
+    monkeypatch.setattr(P.os, 'statvfs', lambda p: Tiny(real(p)))
+    with pytest.warns(UserWarning, match='decoding on 2 threads'):
+        cache = P.FrameCache(workers=2, capacity=64, processes=True)               # 65 slots x 3 MiB >> 8 MiB
+    try:
+        assert cache.procs is None and cache.pool is not None
+        cache.prefetch(paths)
+        for pth in paths:
+            assert np.array_equal(cache(pth), P.LoadImageFromFile.load(pth, rgb=True))
+    finally:
+        cache.close()
+
+
 def test_dataset_tool_cli_and_sharding():
     """tools/test_gaze360_gaze.py keeps the reference's command line (its :20-44) and shards whole videos by frame count."""
     import importlib.util
