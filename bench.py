@@ -69,7 +69,7 @@ CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,
              72: 'pw_single_x3_kernel<16,0,256> (dynamic_layer)',
              50: 'igemm_dma_kernel<float,256,256,128,4,2,2,2,x3>', 51: 'igemm_dma_kernel<float,128,128,128,2,2,2,2,x3>', 52: 'igemm_dma_kernel<float,256,64,128,4,1,2,2,x3>',
              53: 'igemm_dma_kernel<float,128,128,128,4,2,4,1,x3>',
-             73: 'wino_x3_kernel (3x3 / stride 1 as 1-D Winograd F(2,3); FLOPs booked as the direct convolution)'}   # the Winograd FAMILY: wino_x3w_kernel<NB> (one wave per SIMD; grids of >= 130 workgroups) and the small-grid tiles of wino_x3_kernel
+             73: 'wino_x3w_kernel<NB> + small-grid wino_x3_kernel tiles (3x3 / stride 1 as 1-D Winograd F(2,3); FLOPs booked as the direct convolution)'}   # the Winograd FAMILY: wino_x3w_kernel<NB> (one wave per SIMD; grids of >= 130 workgroups) and the small-grid tiles of wino_x3_kernel
 
 
 def parse():

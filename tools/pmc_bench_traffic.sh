@@ -27,7 +27,7 @@ for k, d in agg.items():
     if 'pw_single_x3' in k:      # (round 4 averaged the decoder's dynamic_layer launches -- 105 MB each -- into this symbol: 0.76 x algorithmic)
         name = 'pw_single_x3_kernel<16,0,256> (dynamic_layer)' if re.search(r'pw_single_x3_kernel<16, 0, 256>', k) else 'pw_single_x3_kernel (HBM-bound 256 -> 256 / 1024 convs, register-resident split weights)'
     if 'wino_x3' in k:
-        name = 'wino_x3_kernel (3x3 / stride 1 as 1-D Winograd F(2,3); FLOPs booked as the direct convolution)'
+        name = 'wino_x3w_kernel<NB> + small-grid wino_x3_kernel tiles (3x3 / stride 1 as 1-D Winograd F(2,3); FLOPs booked as the direct convolution)'
     if 'bneck_x3' in k:
         name = 'bneck_x3_kernel (conv2 3x3 + conv3 + next conv1, layer1 / layer2 tails)'
     if 'pw_pair' in k:
