@@ -422,7 +422,7 @@ def roofline_of(rec, precision):
         r['note'] = (f'achieved = ALGORITHMIC FLOP/s (a 3x3 conv booked as the direct convolution); this symbol issues {mult:g} matrix-pipe FLOPs per algorithmic '
                      f'FLOP (three fp16 MFMAs per product' + (', 6 instead of 9 products per output: 1-D Winograd F(2,3)' if dom == 73 else '') + '), so the matrix pipe runs at '
                      f'{round(mult * achieved, 1)} TFLOP/s = {round(mult * achieved / peak, 4)} of the 16-bit MFMA peak.  The chip runs every launch class of this path on its '
-                     '1.4 kW package cap at 1.75 - 2.2 GHz (profiles/r05_a_power_map.md): a pure MFMA loop on random data reaches 0.64 - 0.74 of the nameplate peak there')
+                     '1.4 kW package cap at 1.75 - 2.2 GHz (profiles/r05_a_power_map.md): a pure MFMA loop on dense random fp16 operands is throttled to 1.81 GHz = 0.68 of the nameplate peak (profiles/r05_d_mfma_energy.md)')
     if r['traffic_over_algorithmic'] is not None and r['traffic_over_algorithmic'] < 0.95:
         # PMC bytes below the algorithmic bytes: a calibration or bookkeeping error (round 4: dynamic_layer launches averaged into the
         # pw_single_x3 symbol), not a kernel that moves less than it must -- not printed as a ratio
