@@ -42,8 +42,12 @@ import platform
 import sys
 import time
 
-import numpy as np
-import torch
+# multi-process GPU work on this ROCm stack needs dmabuf IPC (RCCL / tensor sharing across ranks fail with
+# `hipIpcGetMemHandle: invalid argument` otherwise); set before the runtime loads, never overriding the caller
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

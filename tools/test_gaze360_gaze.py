@@ -18,8 +18,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# multi-process GPU work on this ROCm stack needs dmabuf IPC (RCCL / tensor sharing across ranks fail with
+# `hipIpcGetMemHandle: invalid argument` otherwise); set before the runtime loads, never overriding the caller
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcgaze_amd import harness, init_detector, metric  # noqa: E402
