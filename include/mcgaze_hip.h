@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 11
+#define MCG_ABI_VERSION 12
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
 /* MCG_F16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('MCGAZE_LIB') or os.path.join(_HERE, 'libmcgaze_hip.so
 
 MCG_OK = 0
 MCG_F32, MCG_BF16, MCG_F16X3 = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 RES_NONE, RES_ADD, RES_UPSAMPLE_ADD = 0, 1, 2
 FLAG_STAGED_GEMM, FLAG_NO_SPECIALISED = 1, 2
 
