@@ -3,7 +3,7 @@
 # shader engines x 1024 SIMDs), summed over every launch of the symbol.  Prints a markdown table (-> profiles/).
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_mfma; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY -d $OUT/sq -o sq --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel-events none --pipeline 0 --trunk-streams 1 --second-engine none --exact-steps 0 --latency 0 --mae-videos 0 --backbone-clips 0 --precision ${PRECISION:-f16x3} > $OUT/sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY -d $OUT/sq -o sq --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --power-seconds 0 --kernel-events none --pipeline 0 --trunk-streams 1 --second-engine none --exact-steps 0 --latency 0 --mae-videos 0 --backbone-clips 0 --precision ${PRECISION:-f16x3} > $OUT/sq.log 2>&1
 echo "pass rc=$?"
 cd $R
 python - "$OUT" <<'PY'

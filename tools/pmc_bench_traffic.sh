@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_bench; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 240 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o $C --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel-events none --pipeline 0 --trunk-streams 1 --second-engine none --exact-steps 0 --latency 0 --mae-videos 0 --backbone-clips 0 --precision ${PRECISION:-f16x3} > $OUT/$C.log 2>&1
+  timeout 240 rocprofv3 --kernel-trace --pmc $C -d $OUT/$C -o $C --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --power-seconds 0 --kernel-events none --pipeline 0 --trunk-streams 1 --second-engine none --exact-steps 0 --latency 0 --mae-videos 0 --backbone-clips 0 --precision ${PRECISION:-f16x3} > $OUT/$C.log 2>&1
   echo "$C pass rc=$?"
 done
 cd $R
