@@ -58,6 +58,7 @@ FLOPS_PER_CLIP_BACKBONE = 57.22e9  # R-50 alone, 8.174 GFLOP per frame (SURVEY.m
 FLOPS_PER_CLIP = 99.55e9          # 2*MAC over convs + linears + bmms, 7x3x224x224 clip
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+POWER_LIMITED_MATRIX_TFLOPS = 1700.0   # what a pure MFMA loop on dense random fp16 operands holds on this chip (profiles/r05_d_mfma_energy.md)
 PARITY_TOL = 1e-3                 # north_star: (yaw, pitch) within 1e-3 rad of the reference CPU path
 CFG_NAMES = {0: 'igemm_kernel<float,128,64,64,4,1>', 1: 'igemm_kernel<float,128,64,128,4,1>', 2: 'igemm_kernel<float,128,128,64,2,2>',
              3: 'igemm_kernel<float,128,128,128,2,2>', 4: 'igemm_kernel<bf16,128,64,64,4,1>', 5: 'igemm_kernel<bf16,128,64,128,4,1>',
@@ -129,6 +130,52 @@ def cpu_model():
     return platform.processor() or 'unknown'
 
 
+def _cpu_worker(threads, seconds, clip_length, size, seed, ready, go, out):
+    """One process of the cpu_baseline's processes x threads leg: single-clip oracle forwards for `seconds` after the common start."""
+    torch.set_num_threads(threads)
+    from mcgaze_amd import synth
+    from oracle import mcgaze_oracle as orc
+    sd = orc.as_torch(synth.make_state_dict(0))
+    metas = synth.make_img_metas(clip_length, (size, size, 3))
+    clips = synth.make_clips(3 + seed, 2, clip_length, size, size)
+    orc.forward(sd, clips[:clip_length], metas, clip_length)
+    ready.put(seed)
+    go.wait()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        orc.forward(sd, clips[(n % 2) * clip_length:(n % 2 + 1) * clip_length], metas, clip_length)
+        n += 1
+    out.put((n, time.perf_counter() - t0))
+
+
+def cpu_multiprocess(procs, threads, seconds, clip_length, size, timeout=90.0):
+    """`procs` processes x `threads` torch threads, each running single-clip oracle forwards (the reference harness's usage, one model
+    per process) for the same `seconds` window: the host's aggregate rate.  Spawned, not forked (the parent holds a HIP context)."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    ready, out, go = ctx.Queue(), ctx.Queue(), ctx.Event()
+    ps = [ctx.Process(target=_cpu_worker, args=(threads, seconds, clip_length, size, i, ready, go, out), daemon=True) for i in range(procs)]
+    t_spawn = time.perf_counter()
+    for q in ps:
+        q.start()
+    try:
+        for _ in ps:
+            ready.get(timeout=timeout)
+        go.set()
+        res = [out.get(timeout=seconds + timeout) for _ in ps]
+    except Exception as e:   # a child that died or a host without the memory for `procs` models: the leg is reported as absent, with the reason
+        for q in ps:
+            q.terminate()
+        return {'error': f'{type(e).__name__}: {e}', 'processes': procs, 'threads_per_process': threads}
+    for q in ps:
+        q.join(timeout=10)
+    n = sum(r[0] for r in res)
+    el = max(r[1] for r in res)
+    return {'value': round(n / el, 3), 'unit': 'clips/s', 'processes': procs, 'threads_per_process': threads, 'cores': procs * threads,
+            'sample': f'{n} single-clip forwards in {el:.1f} s over {procs} processes (one oracle model each, started together)',
+            'startup_s': round(time.perf_counter() - t_spawn - el, 1)}
+
+
 def cpu_baseline(seconds, clip_length, size):
     """The CPU oracle (fp32 torch restatement proven equal to the reference, tests/test_oracle.py) timed on the host cores on a
     bounded sample of the same synthetic workload: a thread-count sweep picks the fastest setting, then
@@ -173,7 +220,11 @@ def cpu_baseline(seconds, clip_length, size):
             break
     med8 = float(np.median(t8[1:] or t8))
     torch.set_num_threads(default_threads)
-    return {'value': round(1.0 / med, 3), 'unit': 'clips/s', 'cores': best, 'kind': 'port',
+    # the whole host: as many `best`-thread processes as the logical CPUs hold (a single torch process does not scale past ~8 threads on
+    # this model: the sweep above); bounded to 16 processes and ~6 s
+    procs = min(16, ncpu // max(best, 1))
+    multi = cpu_multiprocess(procs, best, min(6.0, seconds * 0.25), clip_length, size) if procs >= 2 else None
+    return {'value': round(1.0 / med, 3), 'unit': 'clips/s', 'cores': best, 'kind': 'port', 'whole_host': multi,
             'sample': f'{len(ts)} single-clip forwards of {clip_length}x3x{size}x{size} (median {med * 1e3:.0f} ms, min {min(ts) * 1e3:.0f} ms), fp32 oracle '
                       f'(oracle/mcgaze_oracle.py) with torch.set_num_threads({best}) -- the fastest of the sweep',
             'thread_sweep_s_per_clip': {str(k): round(v, 3) for k, v in sweep.items()},
@@ -418,6 +469,34 @@ def roofline_of(rec, precision):
          'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_bench_traffic.sh; FETCH_SIZE doubled per '
                            'MI355X_MICROARCH.md); bytes per launch, averaged over the symbol\'s launches; L2-miss traffic incl. Infinity-Cache hits',
          'algorithmic_bytes': 'layer-granular: inputs and residual read once, output written once, weights once (mcg_engine_profile_stop)'}
+    # the three largest symbols of the step, each against BOTH roofs, with the committed counter evidence beside the in-run durations
+    # (the worst large symbol must be visible in the driver's line, not only the dominant one)
+    mj = {}
+    mpath = os.path.join(ROOT, 'profiles', 'pmc_mfma.json')
+    if os.path.exists(mpath):
+        mj = json.load(open(mpath))
+    top = []
+    for c in sorted(by, key=lambda c: -by[c][0])[:3]:
+        t_c, f_c, n_c, b_c = by[c]
+        nm = CFG_NAMES.get(c, str(c))
+        pk = PEAK_F32_TFLOPS if c < 4 else PEAK_BF16_TFLOPS
+        tf = f_c / (t_c * 1e-3) / 1e12
+        mult = (2.0 if c == 73 else 3.0) if precision == 'f16x3' else 1.0
+        tb = (tj.get(nm) or {}).get('hbm_bytes_per_launch')
+        ratio = round(tb / (b_c / n_c), 3) if (tb and b_c) else None
+        top.append({'kernel': nm, 'launches': n_c, 'ms': round(t_c, 3), 'share_of_sampled_ms': round(t_c / sum(v[0] for v in by.values()), 3),
+                    'tflops': round(tf, 1), 'frac': round(tf / pk, 4), 'matrix_pipe_frac': round(mult * tf / pk, 4),
+                    'algorithmic_GBps': round(b_c / 1e9 / (t_c * 1e-3), 0), 'hbm_frac': round(b_c / 1e9 / (t_c * 1e-3) / PEAK_HBM_GBPS, 4),
+                    'mfma_busy': (mj.get(nm) or {}).get('mfma_busy'), 'waves_waiting': (mj.get(nm) or {}).get('waves_waiting'),
+                    'traffic_over_algorithmic': ratio if (ratio is None or ratio >= 0.95) else None})
+    r['top_symbols'] = top
+    r['top_symbols_counter_build_ids'] = {'pmc_mfma': mj.get('_build_id'), 'pmc_traffic': tj.get('_build_id'), 'library': build_id}
+    # the chip's own power-limited matrix rate: a loop of nothing but dense-random-operand fp16 MFMAs is held at 1.81 GHz / 1.30 kW
+    # (profiles/r05_d_mfma_energy.md, tools/lab/micro/mfma_energy.hip, library build 02f203997b6f148b): `frac` read against THAT instead of the nameplate
+    r['power_limited_matrix_peak_tflops'] = POWER_LIMITED_MATRIX_TFLOPS
+    r['power_limited_matrix_peak_source'] = 'profiles/r05_d_mfma_energy.md: pure v_mfma_f32_32x32x16_f16 loop on dense random operands, 1.70 PFLOP/s at 1.30 kW / 1.81 GHz (round 5 measurement, not re-measured in this run)'
+    if precision == 'f16x3':
+        r['matrix_pipe_frac_of_power_limited_peak'] = round((2.0 if dom == 73 else 3.0) * achieved / POWER_LIMITED_MATRIX_TFLOPS, 4)
     if precision == 'f16x3':
         # matrix-pipe FLOPs per algorithmic FLOP: three fp16 MFMAs per product; the Winograd F(2,3) family multiplies 6 instead of 9 times
         # per output (x 2 / 3; F(4,3), engine option winograd = 2: x 1 / 2)

@@ -301,6 +301,10 @@ void mcg_engine_destroy(mcg_engine* e);
  *                     kernel's blocked layout (whole-line stores and loads) instead of [M][C]; internal workspace only, results bit-identical (default 1)
  *   winograd          0/1/2 stride-1 3x3 convs that carry a Winograd copy by wino_x3.hpp (f16x3): 0 off, 1 (default) F(2,3) (mcg_conv_weights.wf), 2 F(4,3)
  *                     on maps whose shape allows it (mcg_conv_weights.wf4; 6 % faster there, four times the operator error), F(2,3) elsewhere
+ *   wino_tile         -1..3 tile of the F(2,3) kernel: -1 (default) by grid size -- the one-wave-per-SIMD tile wino_x3w_kernel on grids of >= 130
+ *                     workgroups --, 0 / 1 / 2 force the 8- / 4-wave tiles of wino_x3_kernel, 3 forces wino_x3w_kernel.  Every tile gives the same
+ *                     bits; 0 is the run-time fallback for wino_x3w_kernel (its hand-issued register loads need a spill-free build, which
+ *                     csrc/check_resources.py enforces at build time)
  *   range_audit       0/1 DEBUG (MCG_F32 / MCG_F16X3; default 0): after every activation tensor the trunk writes, a counting kernel tallies the
  *                     values beyond the fp16 range (|x| > 65504: an f16x3 operand half would saturate there) and the non-finite ones;
  *                     read and reset with mcg_engine_range_audit.  Turning it on allocates the counters (the library's only allocation,

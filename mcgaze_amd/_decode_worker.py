@@ -1,5 +1,5 @@
 """Decode worker of pipeline.FrameCache(processes=True).  Started as a plain child process (`python _decode_worker.py <ring fd> <slot
-bytes> <control fd> <k> <n> <records per queue> <slots>`, the two files being unlinked /dev/shm files inherited as descriptors, not through multiprocessing: no fork of a process that holds a HIP context, no
+bytes> <control fd> <k> <n> <records per queue> <slots> [<directory of the parent's PIL>]`, the two files being unlinked /dev/shm files inherited as descriptors, not through multiprocessing: no fork of a process that holds a HIP context, no
 re-import of the caller's main module, and this file imports neither torch, numpy nor the package).  It serves queue ``k`` of the
 mailbox pipeline._DecodeProcs lays out in the control file: a request record names a ring slot and a path; the file is decoded with
 PIL, its RGB uint8 pixels go into the memory-mapped ring file (/dev/shm) at that slot, then h, w and LAST the state word of the slot
@@ -17,6 +17,8 @@ REC = 1024                             # pipeline._DecodeProcs.REC
 
 
 def main():
+    if len(sys.argv) > 8 and sys.argv[8] and sys.argv[8] not in sys.path:
+        sys.path.append(sys.argv[8])   # where the parent found ITS Pillow (the helper runs with -E -s: no PYTHONPATH, no user site)
     from PIL import Image              # no numpy here: its import alone is 0.2 s of start-up per helper; PIL hands out the pixel bytes itself
     ring_fd, slot_bytes, ctl_fd, k, n, R, slots = map(int, sys.argv[1:8])
     ring = mmap.mmap(ring_fd, 0)

@@ -89,7 +89,7 @@ __device__ __forceinline__ void bnx_step(const char* sl, const bf16x8& xh, const
 // their ds_reads in flight across it.  Two things are written behind a barrier, and neither may meet such a read:
 //   * a ring slot.  The first version refilled, behind barrier kt, the slot of slab kt - 1: its reads usually return long before the DMA
 //     data does (an L2 round trip later), but not always -- with a second engine busy on the device one launch in ~200 came back with a
-//     pixel group computed from a half-overwritten weight fragment (tools/bneck_contention_probe.py, profiles/r03_x_lds_war.md).
+//     pixel group computed from a half-overwritten weight fragment (tools/lab/bneck_contention_probe.py, profiles/r03_x_lds_war.md).
 //     Now every compute-wave barrier drains the wave's LDS reads first, so a slot is free the moment the barrier that ends its group
 //     has been passed.  (Also tried and equally safe: refilling only the slot of the slab before the previous one, bare barriers.
 //     Same box: 0.945 / 0.950 / 0.940 ms for the layer1 identity block without a fix / slack slot / drain + slack slot.)

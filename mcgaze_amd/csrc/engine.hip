@@ -6,7 +6,7 @@
 // side streams the engine owns, forked and joined with events so the call still behaves as one operation on the caller's
 // stream.  Frames are independent, so results do not change; what changes is that the last, partly filled round of
 // workgroups of one range's kernel (layer3 at 14x14 has 343 output tiles for 256 CUs) overlaps with the other range's
-// kernels: 448 frames 9.36 -> 8.75 ms (tools/trunk_two_streams.py).
+// kernels: 448 frames 9.36 -> 8.75 ms (tools/lab/trunk_two_streams.py).
 #include "igemm.hpp"
 #include "pw_pair.hpp"
 #include "pw_single.hpp"
@@ -40,6 +40,9 @@ struct mcg_engine {
   int winograd = 1;            // f16x3: stride-1 3x3 convs with a Winograd-packed weight copy run wino_x3.hpp: 0 off, 1 (default) F(2,3) (mcg_conv_weights.wf),
                                // 2 F(4,3) where the layer's shape allows it and the weights carry that copy (wf4), F(2,3) elsewhere: 6 % faster on
                                // the 56-wide maps for four times the operator error -- opt-in
+  int wino_tile = -1;          // tile of the F(2,3) kernel: -1 (default) by grid size (the one-wave-per-SIMD tile on grids >= 130 workgroups), 0 / 1 / 2 = the 8- and
+                               // 4-wave tiles of wino_x3_kernel forced, 3 = wino_x3w_kernel forced.  Every tile gives the same bits; 0 is the run-time
+                               // fallback for wino_x3w_kernel, whose hand-issued register loads depend on a spill-free build (csrc/check_resources.py)
   // range audit (debug option, f32-storage engines): per activation tensor the trunk writes, how many values lie beyond the fp16 range
   // (|x| > 65504: an f16x3 operand half would saturate) and how many are not finite.  Counters live on the device; read by mcg_engine_range_audit.
   static constexpr int kAuditCap = 256;
@@ -64,7 +67,7 @@ struct mcg_engine {
   bool pw_pair = true;         // layer1 / layer2 (bf16): conv3 (+ residual) and the next block's conv1 as one kernel (pw_pair.hpp)
   std::mutex mu;               // one forward at a time per engine: the fork/join events and side streams are shared state
 };
-// Side-stream candidates are created ONCE per device and shared by every engine of the process.  Measured (tools/leg_order_probe.py):
+// Side-stream candidates are created ONCE per device and shared by every engine of the process.  Measured (tools/lab/leg_order_probe.py):
 // streams created later in a process's life land on hardware queues that serialise against the earlier ones -- a second engine
 // with its own fresh streams ran its trunk 20 % slower than the first (bf16 9.7 -> 11.7 ms per 64 clips) no matter whether the
 // first had been destroyed.  The pool is immutable after creation (guarded by a mutex while it is built and while the per-caller-
@@ -206,6 +209,7 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "bottleneck_fused")) e->bneck_fused = value != 0;
   else if (!strcmp(name, "bottleneck_blocked")) e->bneck_blocked = value != 0;
   else if (!strcmp(name, "winograd")) { MCG_CHECK_ARG(value >= 0 && value <= 2, "winograd must be 0, 1 or 2"); e->winograd = value; }
+  else if (!strcmp(name, "wino_tile")) { MCG_CHECK_ARG(value >= -1 && value <= 3, "wino_tile must be -1 (by grid size) .. 3"); e->wino_tile = value; }
   else if (!strcmp(name, "range_audit")) {
     MCG_CHECK_ARG(e->dt != MCG_BF16 || !value, "range_audit: f32-storage engines only (MCG_F32, MCG_F16X3)");
     if (value && !e->audit_dev) {   // set-up, not the hot path: the only allocation the library ever makes
@@ -391,7 +395,7 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
     wp.H = h; wp.W = w; wp.frames = n; wp.Cin = cw.cin; wp.Cout = cw.cout; wp.relu = relu; wp.wscale = cw.wscale;
     ProfRec* rec = prof_begin(e->ctx, s, 73, (int)M, cw.cout, 9 * cw.cin, 2.0 * M * 9.0 * cw.cin * cw.cout,
                               4.0 * ((double)M * (cw.cin + cw.cout) + 9.0 * cw.cin * cw.cout));
-    const int wrc = launch_wino_x3(s, wp, -1, wg);
+    const int wrc = launch_wino_x3(s, wp, e->wino_tile, wg);
     prof_end(rec, s);
     if (wrc) { mcg_set_error("wino_x3 launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;

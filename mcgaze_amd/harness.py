@@ -228,7 +228,17 @@ def run_annotation(engine, anno, root, pipeline, clip_len=7, stride=4, batch_cli
     pos = {vw: i for i, vw in enumerate(order)}
     lookahead = 2 * batch_clips if lookahead is None else lookahead
     group = max(1, min(batch_clips, 32))                                    # windows staged per preprocessing call
-    cache = FrameCache(workers, capacity=((lookahead if workers > 0 else 0) + group + 2) * clip_len, processes=processes)   # in-line decoding never runs ahead: only the staged group (and the 3-frame overlap) is worth keeping
+    frame_bytes = None
+    if workers > 0 and processes and videos and videos[0]['file_names']:
+        # what a ring slot will really hold: the run's first frame, from its header (no decode) -- the /dev/shm check of the decode ring prices
+        # a slot at that instead of the 3 MiB worst case (a 360 x 360 frame is 390 KB)
+        try:
+            from PIL import Image
+            with Image.open(os.path.join(img_prefix, videos[0]['file_names'][0])) as im:
+                frame_bytes = 2 * im.size[0] * im.size[1] * 3        # x 2: frames of a dataset vary
+        except Exception:
+            frame_bytes = None
+    cache = FrameCache(workers, capacity=((lookahead if workers > 0 else 0) + group + 2) * clip_len, processes=processes, frame_bytes=frame_bytes)   # in-line decoding never runs ahead: only the staged group (and the 3-frame overlap) is worth keeping
     state = dict(ahead=0)
 
     def names_of(vi, wi):

@@ -101,7 +101,11 @@ class _DecodeProcs:
         self.heads = np.zeros(self.n, dtype=np.int64)
         worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_decode_worker.py')
         try:
-            self.procs = [subprocess.Popen([sys.executable, '-I', worker, str(ring_fd), str(slot_bytes), str(fd), str(k), str(self.n), str(self.R), str(self.slots)],
+            # -E -s: the helper ignores PYTHON* variables and the user site (a stray sitecustomize must not slow or break seven start-ups), but it
+            # is TOLD where the parent's own PIL lives -- a Pillow reachable only through PYTHONPATH or `pip install --user` works
+            import PIL
+            pil_dir = os.path.dirname(os.path.dirname(os.path.abspath(PIL.__file__)))
+            self.procs = [subprocess.Popen([sys.executable, '-E', '-s', worker, str(ring_fd), str(slot_bytes), str(fd), str(k), str(self.n), str(self.R), str(self.slots), pil_dir],
                                            stdin=subprocess.DEVNULL, pass_fds=(ring_fd, fd)) for k in range(self.n)]
         finally:
             os.close(fd)
@@ -162,12 +166,13 @@ class FrameCache:
     (run_many calls it once its staging copy is made); a call that needs more distinct frames at once than the cache has slots raises
     instead of handing out a view whose slot a later decode overwrites.  A caller that uses the cache directly calls ``release()`` when it
     is done with the views it holds.  ``processes=True`` needs (capacity + 1) * slot_bytes of /dev/shm at most (pages are touched as slots
-    are used); when the tmpfs cannot back that (a container's default /dev/shm is 64 MB), the cache falls back to decode THREADS with a
-    warning -- a tmpfs that runs out under a mapped write is a SIGBUS in a helper, not an exception.
+    are used: ``frame_bytes``, the decoded size the caller expects, prices a slot in the check; a node's ranks share the tmpfs,
+    LOCAL_WORLD_SIZE); when the tmpfs cannot back that (a container's default /dev/shm is 64 MB), the cache falls back to IN-LINE decoding
+    with a warning -- a tmpfs that runs out under a mapped write is a SIGBUS in a helper, not an exception.
     Only the DECODE is shared: crop draws, geometry and the pixel kernel still run per window, in the caller's order -- results do
     not depend on the cache, the worker count or the worker kind."""
 
-    def __init__(self, workers=0, capacity=512, loader=None, processes=False, slot_bytes=3 << 20):
+    def __init__(self, workers=0, capacity=512, loader=None, processes=False, slot_bytes=3 << 20, frame_bytes=None):
         self.rgb = loader is None                   # our own decode keeps the decoder's RGB order (DevicePipeline.run_many swaps in the kernel)
         self.loader = loader or (lambda path: LoadImageFromFile.load(path, rgb=True))
         self.capacity = max(int(capacity), 1)
@@ -180,16 +185,22 @@ class FrameCache:
             # both shared files are ANONYMOUS: created in /dev/shm, unlinked at once, handed to the helpers as inherited descriptors -- nothing
             # is left behind there however this process ends
             shm = '/dev/shm' if os.path.isdir('/dev/shm') else None
+            # The ring file is sparse: a slot costs the pages its frame touches.  The check prices a slot at ``frame_bytes`` -- the decoded size
+            # the caller expects (harness: the first frame of the run, 390 KB for 360 x 360) -- or, unknown, at the whole slot; the tmpfs is
+            # shared by the ranks of a node, so each rank may count on its share only (LOCAL_WORLD_SIZE).  
+            per_slot = min(int(frame_bytes), self.slot_bytes) if frame_bytes else self.slot_bytes
+            per_slot = (max(per_slot, 1) + 4095) // 4096 * 4096
+            ranks = max(int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1), 1)
             try:
                 vfs = os.statvfs(shm or tempfile.gettempdir())
-                fit = int(vfs.f_bavail * vfs.f_frsize * 0.8) // self.slot_bytes - 1     # slots the file system can back, with a margin
+                fit = int(vfs.f_bavail * vfs.f_frsize * 0.8 / ranks) // per_slot - 1     # slots the file system can back, with a margin
             except OSError:
                 fit = self.capacity
-            if fit < self.capacity + 1:                          # (worst case: every slot touched in full; no half measures -- a ring smaller
-                import warnings                                  #  than one run_many call's frames would only move the failure)
-                warnings.warn(f'FrameCache: {shm or tempfile.gettempdir()} cannot back {self.capacity + 1} ring slots of {self.slot_bytes} bytes '
-                              f'(room for {max(fit, 0)}); decoding on {workers} threads instead of helper processes')
-                processes = False
+            if fit < self.capacity + 1:                          # (no half measures -- a ring smaller than one run_many call's frames would only move the failure)
+                import warnings
+                warnings.warn(f'FrameCache: {shm or tempfile.gettempdir()} cannot back {self.capacity + 1} ring slots of {per_slot} bytes for each of {ranks} rank(s) '
+                              f'(room for {max(fit, 0)}); decoding in line instead of in helper processes')
+                processes, workers = False, 0                    # in line, not threads: decode threads LOSE to in-line decoding (class docstring)
         if workers > 0 and processes:
             import tempfile
             fd, path = tempfile.mkstemp(prefix='mcg_ring_', dir=shm)
@@ -304,13 +315,15 @@ class FrameCache:
             if state == 2:
                 return self.loader(path)                         # larger than a slot: decoded here
             o = e * self.slot_bytes
-            self.held.add(path)                                  # a view of the ring: the slot stays until release()
+            with self.lock:
+                self.held.add(path)                              # a view of the ring: the slot stays until release()
             return self.ring[o:o + h * w * 3].reshape(h, w, 3)
         return self._wait(e) if isinstance(e, concurrent.futures.Future) else e
 
     def release(self):
         """The views handed out so far are no longer read (run_many: copied into the staging buffer): their slots may be evicted again."""
-        self.held.clear()
+        with self.lock:
+            self.held.clear()
 
     def close(self):
         if self.pool is not None:
@@ -584,6 +597,16 @@ class DevicePipeline:
         rngs = rng if isinstance(rng, (list, tuple)) else [rng] * len(windows)   # one generator per window (harness: one per VIDEO), or one for all
         if len(rngs) != len(windows):
             raise ValueError(f'run_many: {len(rngs)} generators for {len(windows)} windows')
+        try:
+            return self._run_many_loaded(windows, rngs, img_prefix, loader, load, rgb_source, arrays, src, plans, bounds, seen, lib, dev, stream)
+        except BaseException:
+            # a TypeError for a non-uint8 frame, a decode error, a staging failure: the ring views handed out so far are not read any more --
+            # without this they stayed pinned and a caller that carried on met 'all cached frames are handed out' later
+            if hasattr(loader, 'release'):
+                loader.release()
+            raise
+
+    def _run_many_loaded(self, windows, rngs, img_prefix, loader, load, rgb_source, arrays, src, plans, bounds, seen, lib, dev, stream):
         for frames, rng in zip(windows, rngs):
             for f in frames:
                 if isinstance(f, str):

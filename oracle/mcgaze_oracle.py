@@ -139,11 +139,12 @@ def roi_align(feat, rois, spatial_scale, out_size=7, sampling_ratio=2):
     xs = x1[:, None] + g[None] * bw[:, None]
     ylo, yhi, ly, hy, yinv = _bilinear_axis(ys, H)
     xlo, xhi, lx, hx, xinv = _bilinear_axis(xs, W)
-    fb = feat[b].reshape(K, C, H * W)
+    ff = feat.reshape(N, C, H * W)
+    bi, ci = b[:, None, None], torch.arange(C)[None, :, None]
 
-    def gather(yi, xi):
-        idx = (yi[:, :, None] * W + xi[:, None, :]).reshape(K, 1, -1).expand(K, C, -1)
-        return fb.gather(2, idx).reshape(K, C, P * s, P * s)
+    def gather(yi, xi):   # the K x C x (P s)^2 taps straight out of feat (a per-RoI copy feat[b] would move K whole maps: 3.2 MB each on P2)
+        idx = (yi[:, :, None] * W + xi[:, None, :]).reshape(K, 1, -1)
+        return ff[bi, ci, idx].reshape(K, C, P * s, P * s)
 
     def w(a, bb):
         return (a[:, :, None] * bb[:, None, :])[:, None]

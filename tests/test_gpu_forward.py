@@ -89,7 +89,10 @@ def test_fp32_engine_matches_reference_golden(golden_dir, engines, engines_train
     boxes = out['boxes'].cpu()
     if bool(g['rescale']):
         boxes = boxes / torch.from_numpy(g['scale_factor'])[None, None, :]
-    np.testing.assert_allclose(boxes.numpy(), g['det_bboxes'][..., :4], atol=5e-2, rtol=1e-4)
+    dbox = float(np.abs(boxes.numpy() - g['det_bboxes'][..., :4]).max())
+    print(f'{name} {precision} boxes: max |d| = {dbox:.2e} px (coordinates up to {float(np.abs(g["det_bboxes"][..., :4]).max()):.0f} px)')
+    # boxes against the REFERENCE's: measured <= 1.3e-3 px on coordinates of several hundred px (both engines, all goldens); 5e-3 px absolute
+    np.testing.assert_allclose(boxes.numpy(), g['det_bboxes'][..., :4], atol=5e-3, rtol=0)
     np.testing.assert_allclose(out['scores'].cpu().numpy(), g['det_bboxes'][..., 4], atol=1e-3)
 
 
@@ -532,6 +535,31 @@ def test_blocked_tensors_between_fused_tails_change_no_bit(engines):
             assert all(torch.equal(oref[k], oout[k]) for k in oref), shape
     finally:
         e.set_option('bottleneck_blocked', 1)
+
+
+def test_winograd_tile_fallback_changes_no_bit(engines):
+    """`wino_tile` (default -1: by grid size): the one-wave-per-SIMD F(2,3) tile keeps hand-issued register loads in flight (its build is
+    gated on zero spills, csrc/check_resources.py -- ADVICE r5); tile 0, the 8-wave kernel with its weights through LDS, is the run-time
+    fallback.  Every tile computes the same bits: pyramid and outputs through the engine must not change, on a batch large enough for the
+    default to pick wino_x3w_kernel (64 frames: 6272 window tiles) and on a single clip."""
+    e = engines['f16x3']
+    try:
+        for shape in ((64, 224, 224), (7, 224, 224), (14, 96, 160)):
+            img = torch.from_numpy(synth.make_clips(71, 1, *shape)).to('cuda:0')
+            e.set_option('wino_tile', -1)
+            ref = [p.clone() for p in e.backbone_fpn(img)]
+            oref = {k: v.clone() for k, v in e.forward(img, 7).items()}
+            for tile in (0, 3):
+                e.set_option('wino_tile', tile)
+                out = e.backbone_fpn(img)
+                oout = e.forward(img, 7)
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, b) for a, b in zip(ref, out)), (shape, tile)
+                assert all(torch.equal(oref[k], oout[k]) for k in oref), (shape, tile)
+    finally:
+        e.set_option('wino_tile', -1)
+    with pytest.raises(Exception):
+        e.set_option('wino_tile', 4)
 
 
 def test_pointwise_stream_kernel_is_bit_identical(engines):

@@ -269,7 +269,7 @@ def test_f16x3_small_weights(eng, wscale):
 
 @pytest.mark.parametrize('xscale', [1e2, 1.0, 1e-1])
 def test_f16x3_activation_magnitudes(eng, xscale):
-    """The ACTIVATION side of the same question (tools/act_scale_probe.py).  An activation below 0.125 has its fp16 low half in the subnormal
+    """The ACTIVATION side of the same question (tools/lab/act_scale_probe.py).  An activation below 0.125 has its fp16 low half in the subnormal
     range -- an ABSOLUTE error of 2^-25, harmless while the tensor as a whole is O(0.1) or larger (every trunk tensor of both synthetic
     weight families: per-layer median |x| 0.17 .. 8.5), not harmless for a tensor that is small as a whole: measured 3.3e-6 of
     scale at |x| ~ 1e-2, 4e-5 at 1e-3 (the f32 kernel: 5e-7 throughout).  Activations are not pre-scaled (a per-tensor scale would make a

@@ -192,10 +192,11 @@ def test_frame_cache_never_recycles_a_view_that_is_still_out(tmp_path):
         cache.close()
 
 
-def test_frame_cache_falls_back_to_threads_when_shm_cannot_back_the_ring(tmp_path, monkeypatch):
-    """the decode ring is a sparse /dev/shm file; a tmpfs that runs out under a mapped write is a SIGBUS in a helper, not an
-    exception (a container's default /dev/shm is 64 MB).  FrameCache checks the free space against the ring's worst case and decodes on
-    threads, with a warning, when it does not fit -- same pixels, no helper processes."""
+def test_frame_cache_falls_back_to_inline_when_shm_cannot_back_the_ring(tmp_path, monkeypatch):
+    """the decode ring is a sparse /dev/shm file; a tmpfs that runs out under a mapped write is a SIGBUS in a helper, not
+    an exception (a container's default /dev/shm is 64 MB).  FrameCache checks the free space -- this rank's share of it (LOCAL_WORLD_SIZE)
+    -- against the ring priced at the caller's expected frame size (else at whole slots) and decodes IN LINE, with a warning, when it does
+    not fit -- same pixels, no helper processes, no threads."""
     import os as _os
     from PIL import Image
     from mcgaze_amd import pipeline as P
@@ -210,15 +211,31 @@ def test_frame_cache_falls_back_to_threads_when_shm_cannot_back_the_ring(tmp_pat
         def __init__(self, st):
             self.f_frsize, self.f_bavail = st.f_frsize, (8 << 20) // st.f_frsize        # 8 MiB free
     monkeypatch.setattr(P.os, 'statvfs', lambda p: Tiny(real(p)))
-    with pytest.warns(UserWarning, match='decoding on 2 threads'):
+    with pytest.warns(UserWarning, match='decoding in line'):
         cache = P.FrameCache(workers=2, capacity=64, processes=True)               # 65 slots x 3 MiB >> 8 MiB
     try:
-        assert cache.procs is None and cache.pool is not None
+        assert cache.procs is None and cache.pool is None
         cache.prefetch(paths)
         for pth in paths:
             assert np.array_equal(cache(pth), P.LoadImageFromFile.load(pth, rgb=True))
     finally:
         cache.close()
+    # priced at the frames the caller expects (20 x 16 x 3 bytes -> one page per slot) the same ring fits the same 8 MiB ...
+    cache = P.FrameCache(workers=2, capacity=64, processes=True, frame_bytes=20 * 16 * 3)
+    try:
+        assert cache.procs is not None
+        cache.prefetch(paths)
+        for pth in paths:
+            assert np.array_equal(cache(pth), P.LoadImageFromFile.load(pth, rgb=True))
+        cache.release()
+    finally:
+        cache.close()
+    # ... but not when 64 ranks of the node share the tmpfs (0.8 x 8 MiB / 64 = 25 pages each)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '64')
+    with pytest.warns(UserWarning, match='64 rank'):
+        cache = P.FrameCache(workers=2, capacity=64, processes=True, frame_bytes=20 * 16 * 3)
+    assert cache.procs is None and cache.pool is None
+    cache.close()
 
 
 def test_dataset_tool_cli_and_sharding():

@@ -9,7 +9,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python - "$OUT" <<'PY'
-import csv, glob, json, re, sys, collections
+import csv, glob, json, os, re, sys, collections
+sys.path.insert(0, os.path.join(os.getcwd(), 'tools'))
+from _symbols import cfg_name_of
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -19,21 +21,7 @@ for sub in ('FETCH_SIZE', 'WRITE_SIZE'):
                 agg[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
 res = {}
 for k, d in agg.items():
-    m = re.search(r'igemm_dma_kernel<unsigned short, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)', k)
-    name = f'igemm_dma_kernel<bf16,{",".join(m.groups())}>' if m else k
-    m = re.search(r'igemm_dma_kernel<float, (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 1>', k)
-    if m:
-        name = f'igemm_dma_kernel<float,{",".join(m.groups())},x3>'
-    if 'pw_single_x3' in k:      # (round 4 averaged the decoder's dynamic_layer launches -- 105 MB each -- into this symbol: 0.76 x algorithmic)
-        name = 'pw_single_x3_kernel<16,0,256> (dynamic_layer)' if re.search(r'pw_single_x3_kernel<16, 0, 256>', k) else 'pw_single_x3_kernel (HBM-bound 256 -> 256 / 1024 convs, register-resident split weights)'
-    if 'wino_x3' in k:
-        name = 'wino_x3w_kernel<NB> + small-grid wino_x3_kernel tiles (3x3 / stride 1 as 1-D Winograd F(2,3); FLOPs booked as the direct convolution)'
-    if 'bneck_x3' in k:
-        name = 'bneck_x3_kernel (conv2 3x3 + conv3 + next conv1, layer1 / layer2 tails)'
-    if 'pw_pair' in k:
-        name = 'pw_pair_kernel (conv3 + next conv1, layer1)'
-    if 'pw_single' in k and 'pw_single_x3' not in k:
-        name = 'pw_single_kernel<16,2,0,128> (dynamic_layer)' if re.search(r'pw_single_kernel<16, 2, 0, 128>', k) else 'pw_single_kernel (HBM-bound 1x1 convs, register-resident weights)'
+    name = cfg_name_of(k)
     e = res.setdefault(name, {'fetch_total': 0.0, 'write_total': 0.0, 'launches_sampled': 0})
     e['fetch_total'] += sum(d['FETCH_SIZE']) * 1024 * 2   # KiB units; x2: gfx950 FETCH_SIZE counts 128-B requests as 64 B
     e['write_total'] += sum(d['WRITE_SIZE']) * 1024

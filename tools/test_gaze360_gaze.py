@@ -57,7 +57,7 @@ def parse_args(argv=None):
     ap.add_argument('--batch-clips', type=int, default=64)
     ap.add_argument('--seed', type=int, default=None)
     ap.add_argument('--per-video-seed', action='store_true',
-                    help='seed the crop draws per VIDEO (seed + video id) instead of one generator per process: the records then do not depend on the number of ranks')
+                    help='seed the crop draws per VIDEO (seed * 1000003 + video id; a non-integer id enters as crc32 of its text) instead of one generator per process: the records then do not depend on the number of ranks')
     ap.add_argument('--workers', type=int, default=8, help='decode helpers that run ahead of the GPU (0 = decode in line); 8 processes measured 9 500 - 9 800 frames/s against 1 900 - 2 000 in line (DESIGN.md section 4)')
     ap.add_argument('--decode', default='processes', choices=['processes', 'threads'], help="kind of decode helper: child processes writing into a /dev/shm ring (default), or host threads")
     ap.add_argument('--ranks-per-gpu', type=int, default=1, help='with torch.distributed.run: consecutive ranks that share one GPU (one consumer process now keeps the device ~80 % busy: more than one per GPU measured slower on the MI355X box; kept for hosts with slower cores)')
@@ -67,6 +67,15 @@ def parse_args(argv=None):
     if a.cfg_options is not None:
         a.cfg_options = {kv.split('=', 1)[0]: parse_value(kv.split('=', 1)[1]) for kv in a.cfg_options}
     return a
+
+
+def _video_key(vid):
+    """--per-video-seed: what a video id adds to the seed.  An INTEGER id (Gaze360's) enters as itself -- round 4's records reproduce --;
+    any other id (a string name) through crc32 of its text (round 5 had switched every id to crc32, silently changing the draws of integer
+    ids: ADVICE r5)."""
+    if isinstance(vid, (int, np.integer)) or (isinstance(vid, str) and vid.lstrip('-').isdigit()):
+        return int(vid)
+    return zlib.crc32(str(vid).encode())
 
 
 def main(argv=None):
@@ -95,7 +104,7 @@ def main(argv=None):
     rng = np.random.RandomState(a.seed + rank) if a.seed is not None else None
     recs = harness.run_annotation(model.engine(), dict(videos=[anno['videos'][i] for i in idx]), a.root, pipe, batch_clips=a.batch_clips, rng=rng, workers=a.workers,
                                   processes=a.decode == 'processes',
-                                  video_rng=(lambda vid: np.random.RandomState(((a.seed or 0) * 1000003 + zlib.crc32(str(vid).encode())) & 0x7fffffff)) if a.per_video_seed else None)
+                                  video_rng=(lambda vid: np.random.RandomState(((a.seed or 0) * 1000003 + _video_key(vid)) & 0x7fffffff)) if a.per_video_seed else None)
     torch.cuda.synchronize()
     t_run = time.time()
     if world > 1:
