@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCG_ABI_VERSION 12
+#define MCG_ABI_VERSION 13
 
 enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MCG_ERR_WORKSPACE = 4 };
 /* MCG_F16X3: the parity-grade fast mode.  Activations, biases and every non-GEMM kernel are exactly those of MCG_F32 (4-byte
@@ -41,7 +41,12 @@ enum { MCG_OK = 0, MCG_ERR_ARG = 1, MCG_ERR_HIP = 2, MCG_ERR_UNSUPPORTED = 3, MC
  * x - hi exact), and each product runs as three fp16 MFMAs (lo.hi + hi.lo + hi.hi) with f32 accumulation.  Operands beyond
  * +-65504 saturate per half (the reference's activations are orders of magnitude below); parts below 6e-8 flush to zero.
  * Measured: 1e-5 rad on (yaw, pitch) against the reference (north_star: 1e-3), within a factor 2 of the MCG_F32 engine. */
-typedef enum { MCG_F32 = 0, MCG_BF16 = 1, MCG_F16X3 = 2 } mcg_dtype;
+/* MCG_F16 (round 6, ABI 13): the 16-bit throughput mode in fp16 -- activations and weights stored as fp16 (11 significant bits instead of
+ * bf16's 8; range +-65504), v_mfma_f32_32x32x16_f16, f32 accumulate, f32 LayerNorm / softmax / boxes.  Every layout, kernel and workspace size
+ * is MCG_BF16's with "bf16" read as "fp16".  Outside north_star's 1e-3 rad on random-weight nets like MCG_BF16, but eight times closer. */
+typedef enum { MCG_F32 = 0, MCG_BF16 = 1, MCG_F16X3 = 2, MCG_F16 = 3 } mcg_dtype;
+/* bytes per activation element */
+#define MCG_ELEM_BYTES(dt) (((dt) == MCG_BF16 || (dt) == MCG_F16) ? 2 : 4)
 typedef void* mcg_stream; /* hipStream_t */
 
 int mcg_abi_version(void);
@@ -72,7 +77,9 @@ enum { MCG_RES_NONE = 0, MCG_RES_ADD = 1, MCG_RES_UPSAMPLE_ADD = 2 };
  * bit-identically (tests/test_gpu_kernels.py) -- they exist for A/B measurements and for those tests. */
 enum {
   MCG_FLAG_STAGED_GEMM = 1,     /* bf16: register-staged contraction kernel instead of the LDS-DMA one */
-  MCG_FLAG_NO_SPECIALISED = 2   /* generic launch sequences instead of conv3x3_c64 / the fused stem / the decoder row-block chains */
+  MCG_FLAG_NO_SPECIALISED = 2,  /* generic launch sequences instead of conv3x3_c64 / the fused stem / the decoder row-block chains */
+  MCG_FLAG_NO_ATTN_BLOCK = 4    /* MCG_F16X3 mcg_stage_forward: the attention passes as in_proj / attention core / out_proj + LayerNorm launches instead of
+                                 * ONE attention-block launch (attn_block_x3.hpp); same bits.  The block reads MCG_SW_IN_PROJ_WF (ABI 13) */
 };
 typedef struct {
   const void* x;        /* NHWC [N,H,W,Cin]                                         */
@@ -165,10 +172,12 @@ enum {
   /* MFMA-fragment-major copies of [32 t][256] matrices for the fused row-block chain / attention block.
    *   MCG_BF16:  bf16 WF[t][ks][lane][e] = W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + e], t < rows / 32, ks < 16, lane < 64, e < 8 --
    *              one wave-wide 16-byte load per (column tile, K-step) is then 1 KiB contiguous.
-   *   MCG_F16X3: REQUIRED for OUT_PROJ / CLS_FC / REG_FC / DYN (the default stage path -- chain_x3.hpp, pw_single_x3.hpp -- reads them;
+   *   MCG_F16X3: REQUIRED for OUT_PROJ / CLS_FC / REG_FC / DYN and -- since ABI 13 -- IN_PROJ (the default stage path -- chain_x3.hpp,
+   *              attn_block_x3.hpp, pw_single_x3.hpp -- reads them;
    *              passing the row-major split-packed pointer again gives WRONG results, not an error): the SPLIT fragment-major form
    *              fp16 WF[t][ks][hl][lane][e], hl = 0 the fp16 high parts, hl = 1 the low parts of the same elements as above
-   *              (mcgaze_amd/packing.py::frag_major_split; 4 bytes per weight).  IN_PROJ_WF is not read by this engine (any pointer).
+   *              (mcgaze_amd/packing.py::frag_major_split; 4 bytes per weight).  IN_PROJ_WF ([768][256], t < 24) is read by the attention block whenever
+   *              3 x clip_length <= 32 (ABI <= 12: not read); flags = MCG_FLAG_NO_ATTN_BLOCK keeps the launch sequence that does not need it.
    *              mcg_stage_forward(flags = MCG_FLAG_NO_SPECIALISED) runs the generic launch sequence, which reads only the row-major
    *              split-packed matrices.
    *   MCG_F32:   ignored (may be given the row-major pointers again). */
@@ -293,6 +302,8 @@ void mcg_engine_destroy(mcg_engine* e);
  *   max_range_frames  >= 0  lowers the frames-per-range cap (0 = what fits the 2 GiB descriptor window)
  *   tile              forces a contraction tile id (0 = heuristic), see mcg_conv_desc.tile
  *   staged_gemm, conv3x3_c64, stem_fused, decoder_chain   0/1 kernel-variant switches (defaults 0, 1, 1, 1)
+ *   decoder_attn_block 0/1 f16x3: both attention passes of a decoder stage (in_proj, attention core, out_proj + residual + LayerNorm, twice) as ONE
+ *                     launch per stage, one clip per workgroup (attn_block_x3.hpp; clips of at most 10 frames); bit-identical to the six launches (default 1)
  *   pointwise_pair    0/1 conv3 (+ residual) of a block and conv1 of the next as one kernel in layer1 (bf16; default 1)
  *   pointwise_stream  0/1 HBM-bound 1x1 convs (layer2, layer3 conv3, P2 / P3 laterals) by the persistent register-resident-weight
  *                     kernel pw_single.hpp (bf16; default 1)

@@ -24,14 +24,16 @@
 // butterflies: 5 LDS round trips per key with __shfl_xor).  Shared by attn_block_kernel (operands in LDS) and attn_core_kernel
 // (operands in global memory), which therefore agree bit for bit.  key(j) / val(j) return a pointer to the 32 contiguous
 // elements of key / value j for this head; out receives 32 elements.
-template <typename T, typename KeyF, typename ValF>
-__device__ __forceinline__ void attend_row_head(const T* __restrict__ qp, KeyF key, ValF val, int L, float scale, T* __restrict__ out) {
+// ld(base, c) loads 16-byte chunk c of the 32 elements at base: linear by default; attn_block_x3.hpp keeps a head's chunks rotated in LDS
+// (bank conflicts) and passes its own -- where a value sits changes no arithmetic.
+template <typename T, typename KeyF, typename ValF, typename LdF>
+__device__ __forceinline__ void attend_row_head(const T* __restrict__ qp, KeyF key, ValF val, int L, float scale, T* __restrict__ out, LdF ld) {
   constexpr int EPC = Elem<T>::kPerChunk, HD = 32;
   float q[HD];
 #pragma unroll
   for (int c = 0; c < HD / EPC; ++c) {
     float t[EPC];
-    chunk_to_f32(*(const uint4*)(qp + c * EPC), t, (T*)nullptr);
+    chunk_to_f32(ld(qp, c), t, (T*)nullptr);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) q[c * EPC + e] = t[e] * scale;
   }
@@ -41,7 +43,7 @@ __device__ __forceinline__ void attend_row_head(const T* __restrict__ qp, KeyF k
 #pragma unroll
     for (int c = 0; c < HD / EPC; ++c) {
       float t[EPC];
-      chunk_to_f32(*(const uint4*)(kp + c * EPC), t, (T*)nullptr);
+      chunk_to_f32(ld(kp, c), t, (T*)nullptr);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) s = fmaf(q[c * EPC + e], t[e], s);
     }
@@ -59,7 +61,7 @@ __device__ __forceinline__ void attend_row_head(const T* __restrict__ qp, KeyF k
 #pragma unroll
     for (int c = 0; c < HD / EPC; ++c) {
       float t[EPC];
-      chunk_to_f32(*(const uint4*)(vp + c * EPC), t, (T*)nullptr);
+      chunk_to_f32(ld(vp, c), t, (T*)nullptr);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) o[c * EPC + e] = fmaf(pj, t[e], o[c * EPC + e]);
     }
@@ -74,10 +76,15 @@ __device__ __forceinline__ void attend_row_head(const T* __restrict__ qp, KeyF k
   }
 }
 
+template <typename T, typename KeyF, typename ValF>
+__device__ __forceinline__ void attend_row_head(const T* __restrict__ qp, KeyF key, ValF val, int L, float scale, T* __restrict__ out) {
+  attend_row_head<T>(qp, key, val, L, scale, out, [](const T* base, int c) { return *(const uint4*)(base + c * Elem<T>::kPerChunk); });
+}
+
 struct AttnBlockParams {
-  const void* x;        // [num_clips * 3T][256] bf16 token rows
-  void* y;              // [num_clips * 3T][256] bf16: rows after both passes
-  const void* w_in;     // in_proj weight [768][256], MFMA-fragment-major (24 column tiles)
+  const void* x;        // [num_clips * 3T][256] bf16 token rows (attn_block_x3_kernel: f32)
+  void* y;              // [num_clips * 3T][256] bf16: rows after both passes (attn_block_x3_kernel: f32)
+  const void* w_in;     // in_proj weight [768][256], MFMA-fragment-major (24 column tiles; attn_block_x3_kernel: the SPLIT fragment-major form)
   const float* b_in;    // [768]
   const void* w_out;    // out_proj weight [256][256], fragment-major
   const float* b_out;   // [256]
@@ -87,13 +94,14 @@ struct AttnBlockParams {
   float scale;          // 1 / sqrt(head_dim)
 };
 
+template <typename T>   // bf16_t or f16_t
 __global__ __launch_bounds__(256, 1) void attn_block_kernel(const AttnBlockParams p) {
   constexpr int D = 256, ROWS = 32, ROWB = D * 2, QKV_LD = 3 * D;
   __shared__ __attribute__((aligned(16))) char s_a[ROWS * ROWB];
   __shared__ __attribute__((aligned(16))) char s_b[ROWS * ROWB];
   __shared__ __attribute__((aligned(16))) char s_att[ROWS * ROWB];
   __shared__ __attribute__((aligned(16))) char s_big[ROWS * QKV_LD * 2];   // qkv (bf16) | out-projection slab (f32, 32 KiB of the 48)
-  bf16_t* s_qkv = (bf16_t*)s_big;
+  T* s_qkv = (T*)s_big;
   float* s_t = (float*)s_big;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rows = 3 * p.T;                                   // <= 32 (checked by the launcher)
@@ -123,8 +131,8 @@ __global__ __launch_bounds__(256, 1) void attn_block_kernel(const AttnBlockParam
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const uint4 a = *(const uint4*)(A + swz(arow, 2 * ks + half));
-      Mma<bf16_t>::run(acc[0], a, bfr[0][ks]);
-      Mma<bf16_t>::run(acc[1], a, bfr[1][ks]);
+      Mma<T>::run(acc[0], a, bfr[0][ks]);
+      Mma<T>::run(acc[1], a, bfr[1][ks]);
     }
   };
   load_b(p.w_in, wave * 2);
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_kernel(const AttnBlockParam
         const int col = u * D + wave * 64 + j * 32 + arow;
         const float bb = p.b_in[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_qkv[mfma32_row(r, lane) * QKV_LD + col] = f2bf(acc[j][r] + bb);
+        for (int r = 0; r < 16; ++r) Elem<T>::st(s_qkv + mfma32_row(r, lane) * QKV_LD + col, acc[j][r] + bb);
       }
     }
     __syncthreads();
@@ -154,10 +162,10 @@ __global__ __launch_bounds__(256, 1) void attn_block_kernel(const AttnBlockParam
       const int i = tid >> 3, h = tid & 7;
       if (i < rows) {
         const int kbase = pass == 0 ? (i / 3) * 3 : i % 3, kstep = pass == 0 ? 1 : 3;
-        __attribute__((aligned(16))) bf16_t o[32];
-        attend_row_head<bf16_t>(s_qkv + i * QKV_LD + h * 32,
-                                [&](int j) { return (const bf16_t*)(s_qkv + (kbase + j * kstep) * QKV_LD + D + h * 32); },
-                                [&](int j) { return (const bf16_t*)(s_qkv + (kbase + j * kstep) * QKV_LD + 2 * D + h * 32); }, L, p.scale, o);
+        __attribute__((aligned(16))) T o[32];
+        attend_row_head<T>(s_qkv + i * QKV_LD + h * 32,
+                           [&](int j) { return (const T*)(s_qkv + (kbase + j * kstep) * QKV_LD + D + h * 32); },
+                           [&](int j) { return (const T*)(s_qkv + (kbase + j * kstep) * QKV_LD + 2 * D + h * 32); }, L, p.scale, o);
 #pragma unroll
         for (int c = 0; c < 4; ++c) *(uint4*)(s_att + swz(i, h * 4 + c)) = *(const uint4*)(o + c * 8);
       } else {
@@ -189,13 +197,13 @@ __global__ __launch_bounds__(256, 1) void attn_block_kernel(const AttnBlockParam
       float v[4] = {t4.x, t4.y, t4.z, t4.w};
       {  // residual = this pass's input row (the mmcv wrapper adds the identity, transformer.py MultiheadAttention)
         const uint2 rr = *(const uint2*)(xin + swz(r, c0 >> 3) + (c0 & 7) * 2);
-        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+        v[0] += H16<T>::lo(rr.x); v[1] += H16<T>::hi(rr.x);
+        v[2] += H16<T>::lo(rr.y); v[3] += H16<T>::hi(rr.y);
       }
       {  // the unfused path stores the projection's output as bf16 before the LayerNorm kernel reads it
-        const uint32_t lo = pack2bf(v[0], v[1]), hi = pack2bf(v[2], v[3]);
-        v[0] = __uint_as_float(lo << 16); v[1] = __uint_as_float(lo & 0xffff0000u);
-        v[2] = __uint_as_float(hi << 16); v[3] = __uint_as_float(hi & 0xffff0000u);
+        const uint32_t lo = H16<T>::pack2(v[0], v[1]), hi = H16<T>::pack2(v[2], v[3]);
+        v[0] = H16<T>::lo(lo); v[1] = H16<T>::hi(lo);
+        v[2] = H16<T>::lo(hi); v[3] = H16<T>::hi(hi);
       }
       const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / D);
       float q = 0.f;
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void attn_block_kernel(const AttnBlockParam
       const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bbv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * rstd * gg[e] + bbv[e];
-      uint2 o = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      uint2 o = make_uint2(H16<T>::pack2(v[0], v[1]), H16<T>::pack2(v[2], v[3]));
       if (r >= rows) o = make_uint2(0, 0);   // padding rows stay zero
       *(uint2*)(xout + swz(r, c0 >> 3) + (c0 & 7) * 2) = o;
       if (pass == 1 && r < rows) *(uint2*)((char*)p.y + (m0 + r) * ROWB + c0 * 2) = o;
@@ -216,7 +224,8 @@ __global__ __launch_bounds__(256, 1) void attn_block_kernel(const AttnBlockParam
 }
 
 static inline bool attn_block_applicable(int T) { return T >= 1 && 3 * T <= 32; }
-static inline int launch_attn_block(hipStream_t s, const AttnBlockParams& p) {
-  hipLaunchKernelGGL(attn_block_kernel, dim3(p.num_clips), dim3(256), 0, s, p);
+static inline int launch_attn_block(hipStream_t s, const AttnBlockParams& p, bool fp16 = false) {
+  if (fp16) hipLaunchKernelGGL(attn_block_kernel<f16_t>, dim3(p.num_clips), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(attn_block_kernel<bf16_t>, dim3(p.num_clips), dim3(256), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

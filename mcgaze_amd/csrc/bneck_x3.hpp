@@ -34,6 +34,14 @@
 #pragma once
 #include "igemm_dma.hpp"
 
+// Measurement builds only (tools/lab/bneck_ablate.sh compiles engine.hip with -DBNX_ABLATE=<mask> into a side library; the product build
+// has 0 and none of this exists in it): which memory stream of the kernel costs what, in time AND joules.  A stream is switched off behind
+// a condition that is false at run time but unknown to the compiler (p.H < 0), so the code and its registers stay what they are:
+//   1 = the weight ring is filled once and never again (the slabs of the first five stay in LDS: real values, wrong weights)
+//   2 = no residual loads     4 = no y / z stores     8 = no window loads after the first tile (its planes stay)
+#ifndef BNX_ABLATE
+#define BNX_ABLATE 0
+#endif
 namespace bnx {
 constexpr int TH = 8, TW = 28, WH = TH + 2, WW = TW + 2;
 constexpr int NPIX = TH * TW, NG = NPIX / 32, WPIX = WH * WW;       // 224 px, 7 groups, 300 window px
@@ -137,9 +145,12 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)s_ring;
     const uint32_t voff = (uint32_t)lane * 16u;
     uint32_t kt_issue = 0, slot_issue = 0;          // slab-in-tile and ring slot of the next slab to issue
+    int issued_total = 0;
     auto issue = [&]() {
       const uint32_t src = kt_issue * SLAB, dst = ring_base + slot_issue * SLAB;
-      static_for<16>([&](auto pc) { lds_dma16<decltype(pc)::value * 1024>(voff, srd_w, src + decltype(pc)::value * 1024, dst); });
+      if (!(BNX_ABLATE & 1) || issued_total < NSLOT || p.H < 0)
+        static_for<16>([&](auto pc) { lds_dma16<decltype(pc)::value * 1024>(voff, srd_w, src + decltype(pc)::value * 1024, dst); });
+      if (BNX_ABLATE & 1) ++issued_total;
       kt_issue = kt_issue + 1 == NS ? 0 : kt_issue + 1;
       slot_issue = slot_issue + 1 == NSLOT ? 0 : slot_issue + 1;
     };
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
     origin(tile, n, ty0, tx0);
     const int gy = ty0 + ty, gx = tx0 + tx;
     const bool valid = gy < p.H && gx < p.W;
-    const bool st_ok = valid, ld_ok = valid;
+    const bool st_ok = valid && ((BNX_ABLATE & 4) ? p.H < 0 : true), ld_ok = valid && ((BNX_ABLATE & 2) ? p.H < 0 : true);
     const long long row = ((long long)n * p.H + (valid ? gy : 0)) * p.W + (valid ? gx : 0);
     // Residual / y addressing.  [M][C]: a lane's 16-byte piece of (chunk oc, channel tile c, quad q) is at row * C + 64 oc + 32 c + 8 q + 4 half -- one
     // instruction touches 32 rows, 32 bytes of each (the two lane halves adjacent).  BLOCKED: per (tile, pixel group) a block of 32 x C floats ordered
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
     const long long sblk = ((long long)tile * NG + g) * (32 * C);
     const uint32_t lane_off = (uint32_t)(pl * 8 + 4 * half);
     const int next = tile + stride;
-    const bool has_next = next < p.total_tiles;
+    const bool has_next = next < p.total_tiles && ((BNX_ABLATE & 8) ? p.H < 0 : true);
 
     // residual rows of chunk 0 (NSRC == 1) / the second source's fragments (NSRC == 2): in flight under the 3x3 phase
     float4 rres[RD][2][4];
@@ -283,9 +294,12 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
 
     // ---------------- conv2: per K half, per tap, per 64-channel output pair one slab (4 K-steps of 16 channels)
     float4 w2nd[KH == 2 ? WIN_ROUNDS : 1];                  // CM = 128: the second K half's window, in flight under the first half
+    const bool win2 = (BNX_ABLATE & 8) ? (p.H < 0 || tile == first) : true;
     if constexpr (KH == 2) {
+      if (win2) {
 #pragma unroll
-      for (int it = 0; it < WIN_ROUNDS; ++it) w2nd[it] = win_load(tile, 1, it);
+        for (int it = 0; it < WIN_ROUNDS; ++it) w2nd[it] = win_load(tile, 1, it);
+      }
     }
     f32x16 acc1[CT1];
 #pragma unroll
@@ -297,8 +311,10 @@ __global__ __launch_bounds__(bnx::NT, 1) void bneck_x3_kernel(const BneckParams 
       constexpr int KHI = decltype(khc)::value;
       if constexpr (KHI == 1) {                             // every wave is done with the first half's planes: park the second half
         bnx_barrier_drained();
+        if (win2) {
 #pragma unroll
-        for (int it = 0; it < WIN_ROUNDS; ++it) win_park(it, w2nd[it]);
+          for (int it = 0; it < WIN_ROUNDS; ++it) win_park(it, w2nd[it]);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       static_for<9>([&](auto tc) {

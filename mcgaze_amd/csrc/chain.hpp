@@ -29,6 +29,7 @@ struct ChainParams {
   ChainStep st[4];
 };
 
+template <typename T>   // bf16_t or f16_t (MCG_F16: the same chain in fp16)
 __global__ __launch_bounds__(256, 1) void mlp_chain_kernel(const ChainParams p) {
   constexpr int D = 256, ROWS = 32, ROWB = D * 2;
   __shared__ __attribute__((aligned(16))) char s_x[ROWS * ROWB];    // kernel input rows (A operand, swizzled)
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_kernel(const ChainParams p) 
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const uint4 a = *(const uint4*)(A + swz(arow, 2 * ks + half));
-      Mma<bf16_t>::run(acc[0], a, bfr[0][ks]);
-      Mma<bf16_t>::run(acc[1], a, bfr[1][ks]);
+      Mma<T>::run(acc[0], a, bfr[0][ks]);
+      Mma<T>::run(acc[1], a, bfr[1][ks]);
     }
     if (si + 1 < p.steps) load_b(si + 1);
 #pragma unroll
@@ -93,13 +94,13 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_kernel(const ChainParams p) 
       float v[4] = {t4.x, t4.y, t4.z, t4.w};
       if (st.res && m0 + r < p.M) {  // (acc + bias) + residual in f32, as the igemm epilogue does
         const uint2 rr = *(const uint2*)((const char*)st.res + (size_t)(m0 + r) * ROWB + c0 * 2);
-        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+        v[0] += H16<T>::lo(rr.x); v[1] += H16<T>::hi(rr.x);
+        v[2] += H16<T>::lo(rr.y); v[3] += H16<T>::hi(rr.y);
       }
       {  // the unfused path stores the linear's output as bf16 and the LayerNorm kernel reads that back: same rounding here
-        const uint32_t lo = pack2bf(v[0], v[1]), hi = pack2bf(v[2], v[3]);
-        v[0] = __uint_as_float(lo << 16); v[1] = __uint_as_float(lo & 0xffff0000u);
-        v[2] = __uint_as_float(hi << 16); v[3] = __uint_as_float(hi & 0xffff0000u);
+        const uint32_t lo = H16<T>::pack2(v[0], v[1]), hi = H16<T>::pack2(v[2], v[3]);
+        v[0] = H16<T>::lo(lo); v[1] = H16<T>::hi(lo);
+        v[2] = H16<T>::lo(hi); v[3] = H16<T>::hi(hi);
       }
       const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / D);
       float q = 0.f;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_kernel(const ChainParams p) 
         const float t = (v[e] - mean) * rstd * gg[e] + bbv[e];
         v[e] = st.relu ? fmaxf(t, 0.f) : t;
       }
-      const uint2 o = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      const uint2 o = make_uint2(H16<T>::pack2(v[0], v[1]), H16<T>::pack2(v[2], v[3]));
       *(uint2*)(s_y + swz(r, c0 >> 3) + (c0 & 7) * 2) = o;
       if (st.dst && m0 + r < p.M) *(uint2*)((char*)st.dst + (size_t)(m0 + r) * ROWB + c0 * 2) = o;
     }
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_kernel(const ChainParams p) 
   }
 }
 
-static inline int launch_mlp_chain(hipStream_t s, const ChainParams& p) {
-  hipLaunchKernelGGL(mlp_chain_kernel, dim3((p.M + 31) / 32), dim3(256), 0, s, p);
+static inline int launch_mlp_chain(hipStream_t s, const ChainParams& p, bool fp16 = false) {
+  if (fp16) hipLaunchKernelGGL(mlp_chain_kernel<f16_t>, dim3((p.M + 31) / 32), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(mlp_chain_kernel<bf16_t>, dim3((p.M + 31) / 32), dim3(256), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

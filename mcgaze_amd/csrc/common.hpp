@@ -24,6 +24,33 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
+// fp16 storage (MCG_F16, round 6): a distinct 2-byte type, so that the 16-bit kernels instantiate once per number format.  f32 -> fp16 is
+// round-to-nearest-even (v_cvt_f16_f32 x 2 + pack); values beyond +-65504 become infinities -- the engine is for checkpoints whose activations
+// stay inside the fp16 range (the f16x3 engine needs the same of its operand halves; mcg_engine_range_audit counts the offenders).
+struct f16_t { uint16_t v; };
+typedef _Float16 f16x2_hw __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_hw __attribute__((ext_vector_type(8)));
+typedef float f32x8_hw __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+  const f32x2_hw v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_hw));
+}
+__device__ __forceinline__ float h2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+
+// A packed pair of 16-bit elements <-> f32, per number format: what the specialised 16-bit kernels (pw_pair, pw_single, conv3x3_c64,
+// stem_fused, chain, attn_block) use where they round an f32 value to the storage type or read one back.
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack2bf(lo, hi); }
+  __device__ static __forceinline__ float lo(uint32_t pk) { return __uint_as_float(pk << 16); }
+  __device__ static __forceinline__ float hi(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+};
+template <> struct H16<f16_t> {
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack2h(lo, hi); }
+  __device__ static __forceinline__ float lo(uint32_t pk) { return h2f((uint16_t)(pk & 0xffffu)); }
+  __device__ static __forceinline__ float hi(uint32_t pk) { return h2f((uint16_t)(pk >> 16)); }
+};
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int kPerChunk = 4;  // elements in a 16-byte chunk
@@ -38,6 +65,13 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+template <> struct Elem<f16_t> {
+  static constexpr int kPerChunk = 8;
+  static constexpr mcg_dtype kDtype = MCG_F16;
+  __device__ static __forceinline__ float ld(const f16_t* p) { return h2f(p->v); }
+  __device__ static __forceinline__ void st(f16_t* p, float v) { p->v = (uint16_t)(pack2h(v, 0.f) & 0xffffu); }
+};
+
 // 16-byte chunk <-> floats
 __device__ __forceinline__ void chunk_to_f32(const uint4& c, float (&v)[4], float*) {
   v[0] = __uint_as_float(c.x); v[1] = __uint_as_float(c.y); v[2] = __uint_as_float(c.z); v[3] = __uint_as_float(c.w);
@@ -48,11 +82,20 @@ __device__ __forceinline__ void chunk_to_f32(const uint4& c, float (&v)[8], bf16
   v[4] = __uint_as_float(c.z << 16); v[5] = __uint_as_float(c.z & 0xffff0000u);
   v[6] = __uint_as_float(c.w << 16); v[7] = __uint_as_float(c.w & 0xffff0000u);
 }
+__device__ __forceinline__ void chunk_to_f32(const uint4& c, float (&v)[8], f16_t*) {
+  const f32x8_hw f = __builtin_convertvector(__builtin_bit_cast(f16x8_hw, c), f32x8_hw);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = f[e];
+}
 __device__ __forceinline__ uint4 f32_to_chunk(const float (&v)[4], float*) {
   return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
 }
 __device__ __forceinline__ uint4 f32_to_chunk(const float (&v)[8], bf16_t*) {
   return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+
+__device__ __forceinline__ uint4 f32_to_chunk(const float (&v)[8], f16_t*) {
+  return make_uint4(pack2h(v[0], v[1]), pack2h(v[2], v[3]), pack2h(v[4], v[5]), pack2h(v[6], v[7]));
 }
 
 // ReLU on a stored 16-byte chunk.  bf16: sign-magnitude patterns order like signed 16-bit integers, so a packed signed max with 0
@@ -67,14 +110,21 @@ __device__ __forceinline__ uint4 relu_chunk(const uint4& c, bf16_t*) {
   return __builtin_bit_cast(uint4, __builtin_elementwise_max(__builtin_bit_cast(s16x8_hw, c), z));
 }
 
+__device__ __forceinline__ uint4 relu_chunk(const uint4& c, f16_t*) { return relu_chunk(c, (bf16_t*)nullptr); }   // fp16 is sign-magnitude too
+
 // One 32x32 MFMA "chunk pair" step: each lane holds 16 bytes of A (row lane&31) and 16 bytes of B
 // (column lane&31) taken from K-chunk 2j + (lane>>5).  bf16: one v_mfma_f32_32x32x16_bf16.
-// f32: four v_mfma_f32_32x32x2_f32 (exact f32 fma chain); the K order inside the pair is
+// fp16: one v_mfma_f32_32x32x16_f16.  f32: four v_mfma_f32_32x32x2_f32 (exact f32 fma chain); the K order inside the pair is
 // permuted identically for A and B, which leaves the dot product's term set unchanged.
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   __device__ static __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<f16_t> {
+  __device__ static __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), acc, 0, 0, 0);
   }
 };
 template <> struct Mma<float> {

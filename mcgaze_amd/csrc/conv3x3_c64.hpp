@@ -32,6 +32,7 @@ constexpr int TRIPS = (WPIX * 8 + 255) / 256;   // 16-byte chunks per thread per
 static_assert(NPIX % 32 == 0, "tile must be whole MFMA row blocks");
 }  // namespace c64
 
+template <typename F>   // number format of the 2-byte elements: bf16_t or f16_t (pointers stay raw 2-byte pointers)
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
                                                           bf16_t* __restrict__ y, int H, int W, int tiles_x, int tiles, int total, int relu) {
   using namespace c64;
@@ -103,14 +104,14 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const bf16_t* __restri
       for (int ks = 0; ks < KS; ++ks) {
         const int tap = ks >> 2, j = ks & 3;
         const uint4 a = *(const uint4*)(a0 + ((tap / 3) * WW + tap % 3) * 16 + 2 * j * PLANE);
-        Mma<bf16_t>::run(acc, a, bfrag[ks]);
+        Mma<F>::run(acc, a, bfrag[ks]);
       }
       char* orow = s_out + (mb * 32 + 4 * half) * 128 + (nb * 32 + row) * 2;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         float v0 = acc[r] + b, v1 = acc[r + 1] + b;
         if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        const uint32_t pk = pack2bf(v0, v1);
+        const uint32_t pk = H16<F>::pack2(v0, v1);
         *(bf16_t*)(orow + ((r & 3) + 8 * (r >> 2)) * 128) = (bf16_t)(pk & 0xffffu);
         *(bf16_t*)(orow + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * 128) = (bf16_t)(pk >> 16);
       }
@@ -131,12 +132,14 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const bf16_t* __restri
 static inline bool conv3x3_c64_applicable(int KH, int KW, int stride, int pad, int Cin, int Cout, bool has_residual, bool has_x2) {
   return KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin == 64 && Cout == 64 && !has_residual && !has_x2;
 }
-static inline int launch_conv3x3_c64(hipStream_t s, const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int relu) {
+static inline int launch_conv3x3_c64(hipStream_t s, const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int relu, bool fp16 = false) {
   const int tiles_y = (H + c64::TH - 1) / c64::TH, tiles_x = (W + c64::TW - 1) / c64::TW;
   const long long total = (long long)tiles_y * tiles_x * N;
   if (total > 0x7fffffffLL) return 1;
   const int grid = (int)(total < 512 ? total : 512);
-  hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, H, W, tiles_x,
-                     tiles_y * tiles_x, (int)total, relu);
+  if (fp16) hipLaunchKernelGGL(conv3x3_c64_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, H, W, tiles_x,
+                               tiles_y * tiles_x, (int)total, relu);
+  else hipLaunchKernelGGL(conv3x3_c64_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)w, bias, (bf16_t*)y, H, W, tiles_x,
+                          tiles_y * tiles_x, (int)total, relu);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

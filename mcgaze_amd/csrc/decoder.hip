@@ -7,6 +7,7 @@
 #include "pw_single.hpp"
 #include "igemm_dma.hpp"
 #include "chain_x3.hpp"
+#include "attn_block_x3.hpp"
 #include "pw_single_x3.hpp"
 
 #include <string.h>
@@ -578,14 +579,15 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
   char* xout[2] = {w.x1, w.x2};
   const bool chain_attn = bf && ctx.chain;
   const bool chain_x3 = dt == MCG_F16X3 && ctx.chain;   // f16x3: the row-block chains in the split arithmetic (chain_x3.hpp)
-  const bool block_attn = chain_attn && attn_block_applicable(clip_length);
-  if (block_attn) {  // both passes, one launch, one clip per workgroup (attn_block.hpp); bit-identical to the loop below
+  // both passes as ONE launch, one clip per workgroup (bf16: attn_block.hpp; f16x3: attn_block_x3.hpp, round 6); bit-identical to the loop below
+  const bool block_attn = (chain_attn || (chain_x3 && ctx.attn_block)) && attn_block_applicable(clip_length);
+  if (block_attn) {
     AttnBlockParams ap;
     memset(&ap, 0, sizeof(ap));
     ap.x = obj_in; ap.y = w.x2; ap.w_in = W[MCG_SW_IN_PROJ_WF]; ap.b_in = f32w[MCG_SW_IN_PROJ_B];
     ap.w_out = W[MCG_SW_OUT_PROJ_WF]; ap.b_out = f32w[MCG_SW_OUT_PROJ_B]; ap.g = f32w[MCG_SW_ATTN_LN_G]; ap.b = f32w[MCG_SW_ATTN_LN_B];
     ap.num_clips = B; ap.T = clip_length; ap.scale = 1.0f / sqrtf(32.f);
-    if (launch_attn_block(s, ap)) { mcg_set_error("attn_block launch failed"); return MCG_ERR_HIP; }
+    if (chain_x3 ? launch_attn_block_x3(s, ap) : launch_attn_block(s, ap)) { mcg_set_error("attn_block launch failed"); return MCG_ERR_HIP; }
   }
   for (int pass = 0; pass < 2 && !block_attn; ++pass) {
     MCG_TRY(launch_linear(s, dt, xin, 256, W[MCG_SW_IN_PROJ_W], f32w[MCG_SW_IN_PROJ_B], nullptr, 0, w.qkv, 768, R, 256, 768, 0, ctx));

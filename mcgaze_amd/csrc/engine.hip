@@ -204,6 +204,7 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "conv3x3_c64")) e->ctx.c64 = value != 0;
   else if (!strcmp(name, "stem_fused")) e->ctx.stem_fused = value != 0;
   else if (!strcmp(name, "decoder_chain")) e->ctx.chain = value != 0;
+  else if (!strcmp(name, "decoder_attn_block")) e->ctx.attn_block = value != 0;
   else if (!strcmp(name, "pointwise_pair")) e->pw_pair = value != 0;
   else if (!strcmp(name, "pointwise_stream")) e->pw_single = value != 0;
   else if (!strcmp(name, "bottleneck_fused")) e->bneck_fused = value != 0;

@@ -273,6 +273,7 @@ struct McgCtx {
   bool c64 = true;           // layer1's conv2 through conv3x3_c64.hpp
   bool stem_fused = true;    // bf16 stem through stem_fused.hpp
   bool chain = true;         // decoder row-block chains (chain.hpp)
+  bool attn_block = true;    // f16x3: both attention passes of a stage as one launch (attn_block_x3.hpp); the bf16 engine's block follows `chain`
   Prof* prof = nullptr;      // armed: every contraction launch is bracketed by an event pair
   static McgCtx from_flags(int tile, int flags) {
     McgCtx c;
@@ -281,6 +282,7 @@ struct McgCtx {
     c.c64 = !(flags & MCG_FLAG_NO_SPECIALISED);
     c.stem_fused = !(flags & MCG_FLAG_NO_SPECIALISED);
     c.chain = !(flags & MCG_FLAG_NO_SPECIALISED);
+    c.attn_block = !(flags & MCG_FLAG_NO_SPECIALISED) && !(flags & MCG_FLAG_NO_ATTN_BLOCK);
     return c;
   }
 };

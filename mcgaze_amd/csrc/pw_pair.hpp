@@ -22,8 +22,9 @@
 // four f32 -> four bf16 (round to nearest even) with ReLU applied on the stored bf16 as a packed signed max (relu_chunk's form:
 // the bits the contraction kernel's epilogue produces)
 typedef short s16x4_hw __attribute__((ext_vector_type(4)));
+template <typename F>   // bf16_t or f16_t: both are sign-magnitude, the packed signed max clears exactly the negative values
 __device__ __forceinline__ uint2 relu_pack4(const float (&v)[4]) {
-  const uint2 o = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+  const uint2 o = make_uint2(H16<F>::pack2(v[0], v[1]), H16<F>::pack2(v[2], v[3]));
   const s16x4_hw z4 = {0, 0, 0, 0};
   return __builtin_bit_cast(uint2, __builtin_elementwise_max(__builtin_bit_cast(s16x4_hw, o), z4));
 }
@@ -45,7 +46,7 @@ struct PwPairParams {
 // per wave and keep the layer-granular launches) and walks pixel tiles with a grid-stride loop, two workgroups per CU.  The next
 // tile's operands (residual rows into the y tile's slots, the A tile(s)) travel HBM -> LDS by `buffer_load ... lds` into the other
 // half of a double buffer while the current tile is contracted, stored and handed on: loads are always in flight.
-template <int NSRC, int C2T>   // NSRC: 1 = one 64-channel A source (identity block), 2 = two (block 0: conv2 output | downsample input)
+template <typename F, int NSRC, int C2T>   // F: bf16_t or f16_t (number format of the 2-byte elements); NSRC: 1 = one 64-channel A source (identity block), 2 = two (block 0: conv2 output | downsample input)
 __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
   constexpr int PX = 64, YROWB = 512, AROWB = 128, KS1 = 4 * NSRC;
   // LDS.  NSRC == 1 (residual present): two y / residual tiles (the residual of the next tile lands while this one is used) + ONE A
@@ -151,10 +152,10 @@ __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
       const char* src = s_a + (ks >> 2) * (PX * AROWB);
       const uint4 x0 = *(const uint4*)(src + a_off(px_l, 2 * (ks & 3) + half));
       const uint4 x1 = *(const uint4*)(src + a_off(32 + px_l, 2 * (ks & 3) + half));
-      Mma<bf16_t>::run(acc[0][0], w3[0][ks], x0);
-      Mma<bf16_t>::run(acc[0][1], w3[0][ks], x1);
-      Mma<bf16_t>::run(acc[1][0], w3[1][ks], x0);
-      Mma<bf16_t>::run(acc[1][1], w3[1][ks], x1);
+      Mma<F>::run(acc[0][0], w3[0][ks], x0);
+      Mma<F>::run(acc[0][1], w3[0][ks], x1);
+      Mma<F>::run(acc[1][0], w3[1][ks], x0);
+      Mma<F>::run(acc[1][1], w3[1][ks], x1);
     }
     // ---- epilogue 1: (acc + bias) + res -> relu -> bf16, 8 bytes (4 channels of one pixel) at a time, into the y tile
 #pragma unroll
@@ -170,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
           float v[4] = {acc[i][j][4 * q] + b4.x, acc[i][j][4 * q + 1] + b4.y, acc[i][j][4 * q + 2] + b4.z, acc[i][j][4 * q + 3] + b4.w};
           if (has_res) {
             const uint2 rr = *(const uint2*)slot;
-            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            v[0] += H16<F>::lo(rr.x); v[1] += H16<F>::hi(rr.x);
+            v[2] += H16<F>::lo(rr.y); v[3] += H16<F>::hi(rr.y);
           }
-          *(uint2*)slot = relu_pack4(v);
+          *(uint2*)slot = relu_pack4<F>(v);
         }
       }
     }
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         const uint4 x = *(const uint4*)(s_y + y_off(pt * 32 + px_l, 2 * ks + half));
-        Mma<bf16_t>::run(acc2[t], w1[t][ks], x);
+        Mma<F>::run(acc2[t], w1[t][ks], x);
       }
     }
     __syncthreads();                                           // y tile fully consumed
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
         const int c0 = ct2 * 32 + 8 * q + 4 * half;
         const float4 b4 = *(const float4*)(s_b1 + c0);
         const float v[4] = {acc2[t][4 * q] + b4.x, acc2[t][4 * q + 1] + b4.y, acc2[t][4 * q + 2] + b4.z, acc2[t][4 * q + 3] + b4.w};
-        *(uint2*)(s_y + px * zrowb + (((c0 >> 3) ^ (px & 7)) << 4) + (c0 & 7) * 2) = relu_pack4(v);
+        *(uint2*)(s_y + px * zrowb + (((c0 >> 3) ^ (px & 7)) << 4) + (c0 & 7) * 2) = relu_pack4<F>(v);
       }
     }
     __syncthreads();
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void pw_pair_kernel(const PwPairParams p) {
 static inline bool pw_pair_applicable(int K1, int K2, int stride2, int C, int C2, long long M) {
   return K1 == 64 && (K2 == 0 || (K2 == 64 && stride2 == 1)) && C == 256 && (C2 == 64 || C2 == 128) && M * 512 < MCG_DMA_MAX_BYTES;
 }
-template <int NSRC, int C2T>
+template <typename F, int NSRC, int C2T>
 static inline void launch_pw_pair_t(hipStream_t s, const PwPairParams& p) {
   constexpr int kLds = (NSRC == 1 ? 2 * 64 * 512 + 64 * 128 : 64 * 512 + 2 * 2 * 64 * 128) + (256 + 128) * 4;
   // per device (a process may hold engines on several GPUs): CU count, and the kernel's dynamic-LDS limit raised once
@@ -234,18 +235,22 @@ static inline void launch_pw_pair_t(hipStream_t s, const PwPairParams& p) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
   if (!cus_of[dev]) {
     hipDeviceProp_t prop;
-    (void)hipFuncSetAttribute((const void*)pw_pair_kernel<NSRC, C2T>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    (void)hipFuncSetAttribute((const void*)pw_pair_kernel<F, NSRC, C2T>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
   const int cus = cus_of[dev];
   const int ntiles = (p.M + 63) / 64;
   const int wgs = 2 * cus;                                     // two workgroups per CU (2 x 80 KiB of LDS fit exactly)
-  hipLaunchKernelGGL((pw_pair_kernel<NSRC, C2T>), dim3(ntiles < wgs ? ntiles : wgs), dim3(256), kLds, s, p);
+  hipLaunchKernelGGL((pw_pair_kernel<F, NSRC, C2T>), dim3(ntiles < wgs ? ntiles : wgs), dim3(256), kLds, s, p);
 }
-static inline int launch_pw_pair(hipStream_t s, const PwPairParams& p) {
-  if (p.K2 == 0 && p.C2 == 64) launch_pw_pair_t<1, 1>(s, p);
-  else if (p.K2 == 0) launch_pw_pair_t<1, 2>(s, p);
-  else if (p.C2 == 64) launch_pw_pair_t<2, 1>(s, p);
-  else launch_pw_pair_t<2, 2>(s, p);
+template <typename F>
+static inline int launch_pw_pair_f(hipStream_t s, const PwPairParams& p) {
+  if (p.K2 == 0 && p.C2 == 64) launch_pw_pair_t<F, 1, 1>(s, p);
+  else if (p.K2 == 0) launch_pw_pair_t<F, 1, 2>(s, p);
+  else if (p.C2 == 64) launch_pw_pair_t<F, 2, 1>(s, p);
+  else launch_pw_pair_t<F, 2, 2>(s, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+static inline int launch_pw_pair(hipStream_t s, const PwPairParams& p, bool fp16 = false) {
+  return fp16 ? launch_pw_pair_f<f16_t>(s, p) : launch_pw_pair_f<bf16_t>(s, p);
 }

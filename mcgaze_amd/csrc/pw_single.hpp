@@ -29,7 +29,7 @@ struct PwSingleParams {
 // K = 16 KS; a workgroup owns N = 128 TPW output channels (TPW 32-channel tiles per wave, 4 waves) of the NSPLIT * N the layer has:
 // NSPLIT workgroups on one XCD (one L2) walk the same pixel tiles, each with its own slice of the weights in registers -- the A tile
 // comes from HBM once and from L2 for the others.  RES: 0 none, 1 same-shape add, 2 nearest-upsample add.
-template <int KS, int TPW, int RES, int NSPLIT>
+template <typename F, int KS, int TPW, int RES, int NSPLIT>
 __global__ __launch_bounds__(256, 2) void pw_single_kernel(const PwSingleParams p) {
   constexpr int PX = 32, K = 16 * KS, N = 128 * TPW, NF = N * NSPLIT, AROWB = 2 * K, YROWB = 2 * N, GROWB = 2 * NF, ACH = AROWB / 16, YCH = YROWB / 16;
   constexpr int ABYTES = PX * AROWB, YBYTES = PX * YROWB;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void pw_single_kernel(const PwSingleParams 
     for (int ks = 0; ks < KS; ++ks) {
       const uint4 x = *(const uint4*)(s_a + a_off(px, 2 * ks + half));
 #pragma unroll
-      for (int i = 0; i < TPW; ++i) Mma<bf16_t>::run(acc[i], w[i][ks], x);
+      for (int i = 0; i < TPW; ++i) Mma<F>::run(acc[i], w[i][ks], x);
     }
     if (RES == 0) __syncthreads();                             // previous tile's y staging fully stored (single y tile)
     // ---- epilogue: (acc + bias) (+ res) -> [relu] -> bf16, 8 bytes (4 channels of one pixel) at a time, into the y tile
@@ -142,10 +142,10 @@ __global__ __launch_bounds__(256, 2) void pw_single_kernel(const PwSingleParams 
         float v[4] = {acc[i][4 * q] + b4.x, acc[i][4 * q + 1] + b4.y, acc[i][4 * q + 2] + b4.z, acc[i][4 * q + 3] + b4.w};
         if (RES) {
           const uint2 rr = *(const uint2*)slot;
-          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          v[0] += H16<F>::lo(rr.x); v[1] += H16<F>::hi(rr.x);
+          v[2] += H16<F>::lo(rr.y); v[3] += H16<F>::hi(rr.y);
         }
-        *(uint2*)slot = p.relu ? relu_pack4(v) : make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        *(uint2*)slot = p.relu ? relu_pack4<F>(v) : make_uint2(H16<F>::pack2(v[0], v[1]), H16<F>::pack2(v[2], v[3]));
       }
     }
     __syncthreads();                                           // y tile complete; the A tile has been consumed by every wave
@@ -163,7 +163,7 @@ static inline bool pw_single_applicable(int K, int N, int res_mode, long long M,
                      (K == 256 && N == 1024) || (K == 512 && N == 256 && res_mode != 1);
   return shape && M >= 64 * 1024 && M * 2 * (K > N ? K : N) < MCG_DMA_MAX_BYTES && res_rows * 2 * N < MCG_DMA_MAX_BYTES;
 }
-template <int KS, int TPW, int RES, int NSPLIT>
+template <typename F, int KS, int TPW, int RES, int NSPLIT>
 static inline void launch_pw_single_t(hipStream_t s, const PwSingleParams& p) {
   constexpr int K = 16 * KS, N = 128 * TPW, AB = 32 * 2 * K, YB = 32 * 2 * N, NYB = RES ? 2 : 1;
   constexpr int BB = TPW == 1 ? 0 : N * 4;
@@ -176,7 +176,7 @@ static inline void launch_pw_single_t(hipStream_t s, const PwSingleParams& p) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
   if (!cus_of[dev]) {
     hipDeviceProp_t prop;
-    (void)hipFuncSetAttribute((const void*)pw_single_kernel<KS, TPW, RES, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    (void)hipFuncSetAttribute((const void*)pw_single_kernel<F, KS, TPW, RES, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
   const int cus = cus_of[dev];
@@ -184,26 +184,27 @@ static inline void launch_pw_single_t(hipStream_t s, const PwSingleParams& p) {
   int wgs = 2 * cus / unit * unit;                              // two workgroups per CU, whole groups of NSPLIT slices x 8 XCDs
   const int need = (ntiles + 7) / 8 * unit;
   if (wgs < unit) wgs = unit;
-  hipLaunchKernelGGL((pw_single_kernel<KS, TPW, RES, NSPLIT>), dim3(need < wgs ? need : wgs), dim3(256), kLds, s, p);
+  hipLaunchKernelGGL((pw_single_kernel<F, KS, TPW, RES, NSPLIT>), dim3(need < wgs ? need : wgs), dim3(256), kLds, s, p);
 }
-static inline int launch_pw_single(hipStream_t s, const PwSingleParams& p, int K, int N, int res_mode) {
+template <typename F>
+static inline int launch_pw_single_f(hipStream_t s, const PwSingleParams& p, int K, int N, int res_mode) {
   if (K == 256 && N == 256) {
-    if (res_mode == 0) launch_pw_single_t<16, 2, 0, 1>(s, p);
-    else if (res_mode == 1) launch_pw_single_t<16, 2, 1, 1>(s, p);
-    else launch_pw_single_t<16, 2, 2, 1>(s, p);
+    if (res_mode == 0) launch_pw_single_t<F, 16, 2, 0, 1>(s, p);
+    else if (res_mode == 1) launch_pw_single_t<F, 16, 2, 1, 1>(s, p);
+    else launch_pw_single_t<F, 16, 2, 2, 1>(s, p);
   } else if (K == 256 && N == 1024) {
-    if (res_mode == 0) launch_pw_single_t<16, 2, 0, 4>(s, p);
-    else if (res_mode == 1) launch_pw_single_t<16, 2, 1, 4>(s, p);
-    else launch_pw_single_t<16, 2, 2, 4>(s, p);
+    if (res_mode == 0) launch_pw_single_t<F, 16, 2, 0, 4>(s, p);
+    else if (res_mode == 1) launch_pw_single_t<F, 16, 2, 1, 4>(s, p);
+    else launch_pw_single_t<F, 16, 2, 2, 4>(s, p);
   } else if (K == 512 && N == 128) {
-    launch_pw_single_t<32, 1, 0, 1>(s, p);
+    launch_pw_single_t<F, 32, 1, 0, 1>(s, p);
   } else if (K == 512 && N == 256) {
-    if (res_mode == 0) launch_pw_single_t<32, 1, 0, 2>(s, p);
-    else launch_pw_single_t<32, 1, 2, 2>(s, p);
+    if (res_mode == 0) launch_pw_single_t<F, 32, 1, 0, 2>(s, p);
+    else launch_pw_single_t<F, 32, 1, 2, 2>(s, p);
   } else {
-    if (res_mode == 0) launch_pw_single_t<8, 4, 0, 1>(s, p);
-    else if (res_mode == 1) launch_pw_single_t<8, 4, 1, 1>(s, p);
-    else launch_pw_single_t<8, 4, 2, 1>(s, p);
+    if (res_mode == 0) launch_pw_single_t<F, 8, 4, 0, 1>(s, p);
+    else if (res_mode == 1) launch_pw_single_t<F, 8, 4, 1, 1>(s, p);
+    else launch_pw_single_t<F, 8, 4, 2, 1>(s, p);
   }
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -212,15 +213,19 @@ static inline int launch_pw_single(hipStream_t s, const PwSingleParams& p, int K
 // 88 MB of output.  The generic kernel spends it in prologues and epilogues (4 K-tiles per 256x128 output tile: 55 us, 1.6 TB/s of
 // writes).  Here: 128 slices of 256 columns, each slice's weights resident in the registers of a few workgroups ("walkers") that
 // split the token tiles between them; the tokens (688 KB) stream out of L2.  Same arithmetic as every pw_single launch: bit-identical.
+static inline int launch_pw_single(hipStream_t s, const PwSingleParams& p, int K, int N, int res_mode, bool fp16 = false) {
+  return fp16 ? launch_pw_single_f<f16_t>(s, p, K, N, res_mode) : launch_pw_single_f<bf16_t>(s, p, K, N, res_mode);
+}
 static inline bool pw_dyn_applicable(int M) { return M >= 256 && (long long)M * 512 < MCG_DMA_MAX_BYTES; }
-static inline int launch_pw_dyn(hipStream_t s, PwSingleParams p) {
+template <typename F>
+static inline int launch_pw_dyn_f(hipStream_t s, PwSingleParams p) {
   constexpr int KS = 16, TPW = 2, NSPLIT = 128, kLds = 32 * 512 + 2 * 32 * 512 + 256 * 4;   // y tile + two A tiles + biases
   static int cus_of[MCG_MAX_DEVICES] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MCG_MAX_DEVICES) dev = 0;
   if (!cus_of[dev]) {
     hipDeviceProp_t prop;
-    (void)hipFuncSetAttribute((const void*)pw_single_kernel<KS, TPW, 0, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    (void)hipFuncSetAttribute((const void*)pw_single_kernel<F, KS, TPW, 0, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
   const int ntiles = (p.M + 31) / 32;
@@ -228,6 +233,9 @@ static inline int launch_pw_dyn(hipStream_t s, PwSingleParams p) {
   if (walkers < 1) walkers = 1;
   if (walkers > ntiles) walkers = ntiles;
   p.many_slices = 1;
-  hipLaunchKernelGGL((pw_single_kernel<KS, TPW, 0, NSPLIT>), dim3(walkers * NSPLIT), dim3(256), kLds, s, p);
+  hipLaunchKernelGGL((pw_single_kernel<F, KS, TPW, 0, NSPLIT>), dim3(walkers * NSPLIT), dim3(256), kLds, s, p);
   return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+static inline int launch_pw_dyn(hipStream_t s, const PwSingleParams& p, bool fp16 = false) {
+  return fp16 ? launch_pw_dyn_f<f16_t>(s, p) : launch_pw_dyn_f<bf16_t>(s, p);
 }

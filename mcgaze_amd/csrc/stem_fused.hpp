@@ -38,6 +38,7 @@ constexpr int IN_BYTES = IT * ITW * 8;
 constexpr int CONV_BYTES = MB * 32 * 128;
 }  // namespace stemf
 
+template <typename F>   // bf16_t or f16_t
 __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict__ img, const bf16_t* __restrict__ w, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ y, int H, int W, int Hc, int Wc, int Ho, int Wo, int tiles_x, int tiles,
                                                          int total) {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < TRIPS; ++j) {
       const int idx = tid + j * 256;
-      if (idx < IT * ITW) *(uint2*)(s_in + idx * 8) = make_uint2(pack2bf(v[j][0], v[j][1]), pack2bf(v[j][2], 0.f));
+      if (idx < IT * ITW) *(uint2*)(s_in + idx * 8) = make_uint2(H16<F>::pack2(v[j][0], v[j][1]), H16<F>::pack2(v[j][2], 0.f));
     }
   };
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const uint4 a = *(const uint4*)(a0 + ((ks >> 1) * ITW + (ks & 1) * 4) * 8);
-        Mma<bf16_t>::run(acc, a, bfrag[ks]);
+        Mma<F>::run(acc, a, bfrag[ks]);
       }
       // C rows of this lane: base + {0,1,2,3, 8..11, 16..19, 24..27}.  Rows 289..319 of the last block are padding: s_conv has
       // room for them, so all 16 values are stored unpredicated, row offsets as ds_write immediates.  Only the bias is applied
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
       char* crow = s_conv + mbase * 128 + (nb * 32 + row) * 2;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const uint32_t pk = pack2bf(acc[r] + b, acc[r + 1] + b);
+        const uint32_t pk = H16<F>::pack2(acc[r] + b, acc[r + 1] + b);
         *(bf16_t*)(crow + ((r & 3) + 8 * (r >> 2)) * 128) = (bf16_t)(pk & 0xffffu);
         *(bf16_t*)(crow + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * 128) = (bf16_t)(pk >> 16);
       }
@@ -157,14 +158,16 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
   }
 }
 
-static inline int launch_stem_fused(hipStream_t s, const float* img, const void* w_stem, const float* bias, void* y, int N, int H, int W) {
+static inline int launch_stem_fused(hipStream_t s, const float* img, const void* w_stem, const float* bias, void* y, int N, int H, int W, bool fp16 = false) {
   const int Hc = H / 2, Wc = W / 2, Ho = (Hc + 2 - 3) / 2 + 1, Wo = (Wc + 2 - 3) / 2 + 1;
   const int tiles_y = (Ho + stemf::PT - 1) / stemf::PT, tiles_x = (Wo + stemf::PT - 1) / stemf::PT;
   const long long total = (long long)tiles_y * tiles_x * N;
   if (total > 0x7fffffffLL) return 1;
   const int grid = (int)(total < 256 * 3 ? total : 256 * 3);  // persistent: 3 workgroups per CU (LDS-limited)
-  hipLaunchKernelGGL(stem_fused_kernel, dim3(grid), dim3(256), 0, s, img, (const bf16_t*)w_stem, bias, (bf16_t*)y, H, W, Hc, Wc, Ho, Wo, tiles_x,
-                     tiles_y * tiles_x, (int)total);
+  if (fp16) hipLaunchKernelGGL(stem_fused_kernel<f16_t>, dim3(grid), dim3(256), 0, s, img, (const bf16_t*)w_stem, bias, (bf16_t*)y, H, W, Hc, Wc, Ho, Wo, tiles_x,
+                               tiles_y * tiles_x, (int)total);
+  else hipLaunchKernelGGL(stem_fused_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, img, (const bf16_t*)w_stem, bias, (bf16_t*)y, H, W, Hc, Wc, Ho, Wo, tiles_x,
+                          tiles_y * tiles_x, (int)total);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

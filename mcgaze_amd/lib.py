@@ -11,9 +11,9 @@ LIB_PATH = os.environ.get('MCGAZE_LIB') or os.path.join(_HERE, 'libmcgaze_hip.so
 
 MCG_OK = 0
 MCG_F32, MCG_BF16, MCG_F16X3 = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 RES_NONE, RES_ADD, RES_UPSAMPLE_ADD = 0, 1, 2
-FLAG_STAGED_GEMM, FLAG_NO_SPECIALISED = 1, 2
+FLAG_STAGED_GEMM, FLAG_NO_SPECIALISED, FLAG_NO_ATTN_BLOCK = 1, 2, 4
 
 # enum order of include/mcgaze_hip.h
 STAGE_KEYS = [

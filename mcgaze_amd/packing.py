@@ -319,6 +319,7 @@ class PackedWeights:
                 HEAD_REG_W=vec(torch.stack([sd[p + f'.{c}_fc_reg.weight'] for c in CLUES])),
                 HEAD_REG_B=vec(torch.stack([sd[p + f'.{c}_fc_reg.bias'] for c in CLUES])))
             raw = dict(OUT_PROJ_W=sd[p + '.attention.attn.out_proj.weight'], CLS_FC_W=sd[p + '.cls_fcs.0.weight'],
+                       IN_PROJ_W=sd[p + '.attention.attn.in_proj_weight'],       # ABI 13: the f16x3 attention block (attn_block_x3.hpp)
                        REG_FC_W=torch.stack([sd[p + f'.reg_fcs.{3 * j}.weight'] for j in range(3)]),
                        DYN_W=sd[q + '.dynamic_layer.weight'][perm])
             for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W', 'IN_PROJ_W', 'DYN_W'):   # fragment-major copies for the fused chain / attention-block kernels

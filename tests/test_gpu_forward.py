@@ -541,10 +541,10 @@ def test_winograd_tile_fallback_changes_no_bit(engines):
     """`wino_tile` (default -1: by grid size): the one-wave-per-SIMD F(2,3) tile keeps hand-issued register loads in flight (its build is
     gated on zero spills, csrc/check_resources.py -- ADVICE r5); tile 0, the 8-wave kernel with its weights through LDS, is the run-time
     fallback.  Every tile computes the same bits: pyramid and outputs through the engine must not change, on a batch large enough for the
-    default to pick wino_x3w_kernel (64 frames: 6272 window tiles) and on a single clip."""
+    default to pick wino_x3w_kernel (63 frames) and on a single clip."""
     e = engines['f16x3']
     try:
-        for shape in ((64, 224, 224), (7, 224, 224), (14, 96, 160)):
+        for shape in ((63, 224, 224), (7, 224, 224), (14, 96, 160)):
             img = torch.from_numpy(synth.make_clips(71, 1, *shape)).to('cuda:0')
             e.set_option('wino_tile', -1)
             ref = [p.clone() for p in e.backbone_fpn(img)]

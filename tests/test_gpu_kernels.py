@@ -747,6 +747,30 @@ def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T):
         assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), name
 
 
+@pytest.mark.parametrize('B,T', [(1, 7), (5, 3), (11, 1), (2, 10), (1, 11), (13, 7), (64, 7)])
+def test_attn_block_x3_matches_unfused_bitwise(eng, sd, B, T):
+    """f16x3 (round 6): attn_block_x3.hpp -- both attention passes of a stage (in_proj, attention core, out_proj + residual + LayerNorm, twice) as
+    ONE launch, one clip per workgroup, for 3 T <= 32 (T = 11 keeps the launch sequence) -- against the sequence it replaces
+    (MCG_FLAG_NO_ATTN_BLOCK: igemm_dma in_proj, attn_core_kernel, mlp_chain_x3 per pass) and against the generic launch sequence
+    (MCG_FLAG_NO_SPECIALISED: no chains at all): same K order, same order of the three split terms, the same f32 rounding points, the
+    same attention device function, ln_kernel's reduction order -- every output of the stage must be bit-identical in all three."""
+    from mcgaze_amd.packing import PackedWeights
+    from mcgaze_amd import lib as L
+    pw = PackedWeights(sd, dtype=torch.float32, split=True)
+    N = B * T
+    g = torch.Generator().manual_seed(400 + N)
+    roi = (torch.randn(N * 3, 49, 256, generator=g) * 3).to('cuda:0')
+    obj = torch.randn(N, 3, 256, generator=g).to('cuda:0')
+    boxes = (torch.tensor([[20., 30., 200., 210.], [60., 50., 160., 150.], [90., 60., 130., 100.]])[None].repeat(N, 1, 1) + torch.randn(N, 3, 4, generator=g)).to('cuda:0')
+    outs = {}
+    for mode, flags in (('generic', L.FLAG_NO_SPECIALISED), ('chains', L.FLAG_NO_ATTN_BLOCK), ('block', 0)):
+        outs[mode] = [t.clone() for t in eng.stage_forward(pw.stages[2], roi, obj, boxes, T, split=True, flags=flags)]
+    torch.cuda.synchronize()
+    for name, a, b, c in zip(('obj', 'boxes', 'cls'), outs['generic'], outs['chains'], outs['block']):
+        assert torch.equal(b, c), ('block vs chains', name, float((b - c).abs().max()))
+        assert torch.equal(a, b), ('chains vs generic', name, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize('kind', KINDS)
 def test_gaze_head(eng, sd, kind):
     from mcgaze_amd.packing import PackedWeights
