@@ -14,8 +14,9 @@ One run reports, in ONE JSON line printed by rank 0:
     measured deviation from the CPU oracle on clip 0 (`max_abs_dev_yaw_pitch_clip0`, `within_tolerance`);
   * `verified`: after the timed loop, the last batch is re-run strictly serially (one trunk stream, no batch pipeline) and
     must reproduce the timed schedule's outputs BIT FOR BIT;
-  * `throughput_engine`: the --second-engine (default bf16: 16-bit storage and MFMA) timed the same way, flagged
-    `within_tolerance: false` when its measured deviation exceeds the tolerance -- reported, never the headline;
+  * `throughput_engine`: the first --second-engine (default f16: fp16 storage and MFMA, MCG_F16) timed the same way, flagged
+    `within_tolerance: false` when its measured deviation exceeds the tolerance, with the MAE clause of north_star measured beside it
+    (`mae_shift_deg`, `within_0p05_deg`: from `mae_proxy`) -- reported, never the headline; `other_engines`: further ones (default bf16);
   * `roofline`: dominant contraction kernel, from HIP events around every contraction launch of one UNTIMED sampling step, with the
     algorithmic HBM bytes of every launch beside the PMC traffic;
   * `backbone`: BASELINE.json configs[1] -- R-50 backbone only at 32 clips x 7 frames, both engines;
@@ -87,10 +88,11 @@ def parse():
                     help='strong scaling: a FIXED number of clips per step, sharded over the ranks (e.g. 512 = BASELINE.json configs[3]); 0 = weak scaling with --clips-per-gpu')
     ap.add_argument('--clip-length', type=int, default=7)
     ap.add_argument('--size', type=int, default=224)
-    ap.add_argument('--precision', default='f16x3', choices=['bf16', 'fp32', 'f16x3'],
+    ap.add_argument('--precision', default='f16x3', choices=['bf16', 'f16', 'fp32', 'f16x3'],
                     help='the HEADLINE engine; f16x3 (default) is the one inside north_star\'s 1e-3 tolerance')
-    ap.add_argument('--second-engine', '--parity-engine', dest='second_engine', default='bf16', choices=['bf16', 'f16x3', 'fp32', 'none'],
-                    help='second engine timed in the same run and reported as a sub-object; skipped when equal to --precision')
+    ap.add_argument('--second-engine', '--parity-engine', dest='second_engine', default='f16,bf16',
+                    help="engines timed in the same run beside the headline, comma-separated (of bf16, f16, f16x3, fp32; 'none' = no second engine).  The first "
+                         "is reported as `throughput_engine` (default f16: fp16 storage and MFMA, MCG_F16), the others under `other_engines`; one equal to --precision is skipped")
     ap.add_argument('--exact-steps', type=int, default=10, help='timed steps of the exact_engine leg (fp32 engine, rank 0, N = 1 only; 0 disables)')
     ap.add_argument('--second-steps', '--parity-steps', dest='second_steps', type=int, default=0, help='timed steps of the second engine (0 = steps)')
     ap.add_argument('--backbone-clips', type=int, default=32, help='BASELINE.json configs[1]: clips of the backbone-only sub-measurement (0 disables)')
@@ -118,6 +120,22 @@ def parse():
     ap.add_argument('--kernel-events', default='sample', choices=['sample', 'none'],
                     help="'sample': bracket every contraction-kernel launch of one UNTIMED step with HIP events (roofline)")
     return ap.parse_args()
+
+
+def cpu_quota_cores():
+    """CPU time this container may use, in cores (cgroup v2 cpu.max / v1 cfs quota); None = unlimited or unknown.  A host that shows 256
+    logical CPUs behind a 16-core quota runs 8 x 16 threads SLOWER than 1 x 16 (CFS throttling): the whole-host leg is sized by this."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        return None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_model():
@@ -231,13 +249,18 @@ def cpu_baseline(seconds, clip_length, size):
     torch.set_num_threads(default_threads)
     # the whole host: as many `best`-thread processes as the logical CPUs hold (a single torch process does not scale past ~8 threads on
     # this model: the sweep above); bounded to 16 processes and ~6 s
-    procs = min(16, max(1, (ncpu // 2 if ncpu >= 32 else ncpu) // max(best, 1)))     # the first half of the logical CPUs: one hardware thread per core on an SMT-2 host
-    multi = cpu_multiprocess(procs, best, min(6.0, seconds * 0.25), clip_length, size) if procs >= 2 else None
+    quota = cpu_quota_cores()
+    usable = ncpu // 2 if ncpu >= 32 else ncpu                                        # the first half of the logical CPUs: one hardware thread per core on an SMT-2 host
+    if quota is not None:
+        usable = min(usable, int(quota))
+    procs = min(16, max(1, usable // max(best, 1)))
+    multi = cpu_multiprocess(procs, best, min(6.0, seconds * 0.25), clip_length, size) if procs >= 2 else \
+        {'skipped': f'{usable} usable cores (logical CPUs {ncpu}, cgroup CPU quota {quota}) hold one {best}-thread process only: the single-process figure IS the host\'s'}
     return {'value': round(1.0 / med, 3), 'unit': 'clips/s', 'cores': best, 'kind': 'port', 'whole_host': multi,
             'sample': f'{len(ts)} single-clip forwards of {clip_length}x3x{size}x{size} (median {med * 1e3:.0f} ms, min {min(ts) * 1e3:.0f} ms), fp32 oracle '
                       f'(oracle/mcgaze_oracle.py) with torch.set_num_threads({best}) -- the fastest of the sweep',
             'thread_sweep_s_per_clip': {str(k): round(v, 3) for k, v in sweep.items()},
-            'logical_cpus': ncpu, 'cpu_model': cpu_model(), 'torch_default_threads': default_threads,
+            'logical_cpus': ncpu, 'cgroup_cpu_quota_cores': quota, 'cpu_model': cpu_model(), 'torch_default_threads': default_threads,
             'batched8_value': round(8.0 / med8, 3), 'batched8_sample': f'{len(t8)} forwards of 8 clips, median {med8:.2f} s (first is warm-up when more than one)'}
 
 
@@ -520,6 +543,8 @@ def roofline_of(rec, precision):
         # pw_single_x3 symbol), not a kernel that moves less than it must -- not printed as a ratio
         r['traffic_note'] = f"PMC traffic / algorithmic bytes = {r['traffic_over_algorithmic']} < 0.95: counter calibration or symbol bookkeeping is off; ratio withheld"
         r['traffic_over_algorithmic'] = None
+    if precision == 'f16':   # the 16-bit cfg ids are named after their bf16 instantiation; this engine runs the fp16 one of the same template
+        r = json.loads(json.dumps(r).replace('<bf16,', '<f16,'))
     if step_bytes:
         r['hbm_step'] = {'bytes': int(step_bytes), 'contraction_launches_covered': covered, 'of': len(rec), 'peak_GBps': PEAK_HBM_GBPS,
                          'algorithmic_bytes': int(algo_step), 'over_algorithmic': round(step_bytes / algo_step, 3) if algo_step else None,
@@ -883,25 +908,37 @@ def main():
 
     WHAT = {'f16x3': 'f32 activations, weights split-packed into fp16 high / low halves, three fp16 MFMAs per product, f32 accumulate (include/mcgaze_hip.h MCG_F16X3); the library default',
             'bf16': 'bf16 activations and weights, bf16 MFMA, f32 accumulate; f32 LayerNorm / softmax / boxes (MCG_BF16); explicit opt-in',
+            'f16': 'fp16 activations and weights (11 significant bits; range +-65504), fp16 MFMA, f32 accumulate; f32 LayerNorm / softmax / boxes (MCG_F16, round 6): '
+                   'the bf16 engine\'s kernels and layouts in fp16; explicit opt-in',
             'fp32': 'f32 storage and f32 MFMA (MCG_F32)'}
     leg, head, head_back = run_engine(a.precision, a.steps, a.warmup)
     engines_for_mae = {a.precision: leg.eng}
-    second, second_back = None, None
-    if a.second_engine not in ('none', a.precision) and a.workload == 'full':
+    second, second_back, others, others_back = None, None, {}, {}
+    seconds = [p for p in dict.fromkeys(a.second_engine.split(',')) if p not in ('none', '', a.precision)]
+    for p in seconds:
+        assert p in WHAT, f'--second-engine: unknown engine {p!r}'
+    a.second_engine = seconds[0] if seconds else 'none'
+    for i, prec in enumerate(seconds if a.workload == 'full' else []):
         del leg.runner
         leg.runner = None
-        sleg, second, second_back = run_engine(a.second_engine, a.second_steps or a.steps, max(2, a.warmup))
-        if second.get('roofline'):
-            second['roofline'].pop('launches', None)       # the per-launch listing is the headline engine's
-        second = dict({'dtype': a.second_engine, 'what': WHAT[a.second_engine],
-                       'oracle': 'oracle/mcgaze_oracle.py (fp32 CPU restatement pinned to the reference goldens) on clip 0 of this batch'}, **second)
-        engines_for_mae[a.second_engine] = sleg.eng
+        sleg, res_i, back_i = run_engine(prec, a.second_steps or a.steps, max(2, a.warmup))
+        if res_i.get('roofline'):
+            res_i['roofline'].pop('launches', None)       # the per-launch listing is the headline engine's
+        res_i = dict({'dtype': prec, 'what': WHAT[prec],
+                      'oracle': 'oracle/mcgaze_oracle.py (fp32 CPU restatement pinned to the reference goldens) on clip 0 of this batch'}, **res_i)
+        engines_for_mae[prec] = sleg.eng
         del sleg.runner
         sleg.runner = None
+        if i == 0:
+            second, second_back = res_i, back_i
+        else:
+            if res_i.get('roofline'):                    # the first two engines carry the full roofline object; further ones its headline numbers
+                res_i['roofline'] = {k: res_i['roofline'].get(k) for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'launches_per_step', 'avg_launch_ms')}
+            others[prec], others_back[prec] = res_i, back_i
 
     # ------------------------------------------------------------------ the exact engine beside the headline
     exact = None
-    if world == 1 and a.exact_steps > 0 and a.workload == 'full' and 'fp32' not in (a.precision, a.second_engine):
+    if world == 1 and a.exact_steps > 0 and a.workload == 'full' and 'fp32' not in [a.precision] + seconds:
         del leg.runner
         leg.runner = None
         xleg, exact, _ = run_engine('fp32', a.exact_steps, 2)
@@ -969,7 +1006,9 @@ def main():
         if strong is not None:
             line['strong_scaling'] = strong
         if second is not None:
-            line['throughput_engine' if a.second_engine == 'bf16' else 'second_engine'] = second
+            line['throughput_engine' if a.second_engine in ('bf16', 'f16') else 'second_engine'] = second
+        if others:
+            line['other_engines'] = others
         if exact is not None:
             line['exact_engine'] = exact
         if head_back is not None:
@@ -977,17 +1016,29 @@ def main():
                                         f'{FLOPS_PER_CLIP_BACKBONE / 1e9:.2f} GFLOP per clip, two concurrent frame ranges', a.precision: head_back}
             if second_back is not None:
                 line['backbone'][a.second_engine] = second_back
+            for pk, bk in others_back.items():
+                if bk is not None:
+                    line['backbone'][pk] = bk
         if world == 1 and a.mae_videos > 0 and a.workload == 'full':
             from mcgaze_amd.engine import HipEngine
             if 'fp32' not in engines_for_mae:
                 engines_for_mae['fp32'] = HipEngine(synth.make_state_dict(0), precision='fp32', device=dev)
             line['mae_proxy'] = mae_proxy(engines_for_mae, dev, a.mae_videos, T)
+            for key in ('throughput_engine', 'second_engine'):   # north_star's MAE clause, measured in this run, beside the engine it is about
+                if key in line and line[key]['dtype'] in line['mae_proxy']['engines']:
+                    m = line['mae_proxy']['engines'][line[key]['dtype']]
+                    line[key]['mae_shift_deg'] = m['shift_deg']
+                    line[key]['within_0p05_deg'] = m['within_0p05_deg']
+            for pk, ok in (line.get('other_engines') or {}).items():
+                if pk in line['mae_proxy']['engines']:
+                    ok['mae_shift_deg'] = line['mae_proxy']['engines'][pk]['shift_deg']
+                    ok['within_0p05_deg'] = line['mae_proxy']['engines'][pk]['within_0p05_deg']
         engines_for_mae.clear()
         if world == 1 and a.host_input_steps > 0 and a.workload == 'full' and a.pipeline:
             line['host_input'] = host_input_leg(leg.eng, dev, B, T, a.size, a.host_input_steps)
         if world == 1 and a.latency and a.workload == 'full':
             del leg
-            line['latency_single_clip'] = single_clip_latency([p for p in dict.fromkeys([a.precision, a.second_engine]) if p != 'none'], dev, T, a.size)
+            line['latency_single_clip'] = single_clip_latency([p for p in dict.fromkeys([a.precision] + seconds) if p != 'none'], dev, T, a.size)
         if world == 1 and a.cpu_seconds > 0:
             line['cpu_baseline'] = cpu_baseline(a.cpu_seconds, T, a.size)
             if 'latency_single_clip' in line:

@@ -3,7 +3,8 @@ config file or Config, drop train_cfg / pretrained init, load the checkpoint wit
 ``^module\\.`` -> '' (and the leftover ``mask_head`` -> ``blink_head`` rule), set ``model.cfg`` and
 ``model.CLASSES``, move to the device, ``eval()``.  ``precision`` selects the HIP engine: 'f16x3' (default, parity-grade
 fast mode: the reference is fp32 everywhere and this mode reproduces it to < 1e-4 rad), 'fp32' (exact reference mode) or
-'bf16' (throughput mode, explicit opt-in: outside the 1e-3 parity tolerance on random-weight nets)."""
+'f16' / 'bf16' (16-bit throughput modes, fp16 or bf16 storage and MFMA; explicit opt-in: outside the 1e-3 parity tolerance on
+random-weight nets, fp16 eight times closer than bf16)."""
 import re
 import warnings
 

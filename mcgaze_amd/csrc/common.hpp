@@ -173,6 +173,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// ---------------------------------------------------------------- dtype helpers of the host launchers
+static inline bool mcg_is16(mcg_dtype dt) { return dt == MCG_BF16 || dt == MCG_F16; }   // 2-byte activation storage
+
 // ---------------------------------------------------------------- host side error plumbing
 void mcg_set_error(const char* fmt, ...);
 #define MCG_CHECK_ARG(cond, ...)        \

@@ -103,6 +103,7 @@ static int launch_ln(hipStream_t s, mcg_dtype dt, const LnParams& p) {
   MCG_CHECK_ARG(p.D % 64 == 0 && p.D <= 256 && p.M > 0, "layernorm: unsupported width %d", p.D);
   dim3 grid((p.M + 3) / 4);
   if (dt == MCG_BF16) hipLaunchKernelGGL(ln_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else if (dt == MCG_F16) hipLaunchKernelGGL(ln_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(ln_kernel<float>, grid, dim3(256), 0, s, p);
   MCG_CHECK_LAUNCH("layernorm");
   return MCG_OK;
@@ -529,7 +530,7 @@ struct StageWs {
 };
 static const int kFcSlices = 16;
 static StageWs stage_layout(mcg_dtype dt, int N, char* base) {
-  const size_t es = dt == MCG_BF16 ? 2 : 4, R = (size_t)N * 3;
+  const size_t es = mcg_is16(dt) ? 2 : 4, R = (size_t)N * 3;
   StageWs w;
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
@@ -571,7 +572,7 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
   const int R = N * 3, B = N / clip_length;
   const float* f32w[MCG_SW_COUNT];
   for (int i = 0; i < MCG_SW_COUNT; ++i) f32w[i] = (const float*)W[i];
-  const bool bf = dt == MCG_BF16;
+  const bool bf = mcg_is16(dt), h16 = dt == MCG_F16;   // bf: 2-byte storage (MCG_BF16 or MCG_F16: the same launch sequence); h16: fp16 instantiations
   const size_t es = bf ? 2 : 4;
 
   // --- spatial then temporal self-attention with SHARED weights and LayerNorm (gaze_stqi_head.py:148-166)
@@ -587,11 +588,12 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
     ap.x = obj_in; ap.y = w.x2; ap.w_in = W[MCG_SW_IN_PROJ_WF]; ap.b_in = f32w[MCG_SW_IN_PROJ_B];
     ap.w_out = W[MCG_SW_OUT_PROJ_WF]; ap.b_out = f32w[MCG_SW_OUT_PROJ_B]; ap.g = f32w[MCG_SW_ATTN_LN_G]; ap.b = f32w[MCG_SW_ATTN_LN_B];
     ap.num_clips = B; ap.T = clip_length; ap.scale = 1.0f / sqrtf(32.f);
-    if (chain_x3 ? launch_attn_block_x3(s, ap) : launch_attn_block(s, ap)) { mcg_set_error("attn_block launch failed"); return MCG_ERR_HIP; }
+    if (chain_x3 ? launch_attn_block_x3(s, ap) : launch_attn_block(s, ap, h16)) { mcg_set_error("attn_block launch failed"); return MCG_ERR_HIP; }
   }
   for (int pass = 0; pass < 2 && !block_attn; ++pass) {
     MCG_TRY(launch_linear(s, dt, xin, 256, W[MCG_SW_IN_PROJ_W], f32w[MCG_SW_IN_PROJ_B], nullptr, 0, w.qkv, 768, R, 256, 768, 0, ctx));
-    if (bf) launch_attn<bf16_t>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
+    if (h16) launch_attn<f16_t>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
+    else if (bf) launch_attn<bf16_t>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
     else launch_attn<float>(s, w.qkv, w.att, pass == 0 ? N : B * 3, pass == 0 ? 3 : clip_length, pass, clip_length);
     MCG_CHECK_LAUNCH("attn_core");
     if (chain_attn || chain_x3) {  // out_proj + residual + LayerNorm as one launch
@@ -600,7 +602,7 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
       cp.x = w.att; cp.M = R; cp.steps = 1;
       cp.st[0].W = W[MCG_SW_OUT_PROJ_WF]; cp.st[0].bias = f32w[MCG_SW_OUT_PROJ_B]; cp.st[0].res = xin;
       cp.st[0].g = f32w[MCG_SW_ATTN_LN_G]; cp.st[0].b = f32w[MCG_SW_ATTN_LN_B]; cp.st[0].dst = xout[pass]; cp.st[0].from_input = 1;
-      if (chain_x3 ? launch_mlp_chain_x3(s, cp) : launch_mlp_chain(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
+      if (chain_x3 ? launch_mlp_chain_x3(s, cp) : launch_mlp_chain(s, cp, h16)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
     } else {
       MCG_TRY(launch_linear(s, dt, w.att, 256, W[MCG_SW_OUT_PROJ_W], f32w[MCG_SW_OUT_PROJ_B], xin, 256, w.t, 256, R, 256, 256, 0, ctx));
       MCG_TRY(launch_ln(s, dt, ln_simple(w.t, f32w[MCG_SW_ATTN_LN_G], f32w[MCG_SW_ATTN_LN_B], 0, xout[pass], R, 256)));
@@ -614,7 +616,7 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
     memset(&pp, 0, sizeof(pp));
     pp.a = w.x2; pp.wf = W[MCG_SW_DYN_WF]; pp.bias = f32w[MCG_SW_DYN_B]; pp.y = w.params; pp.M = R; pp.Ho = 1; pp.Wo = 1;
     ProfRec* rec = prof_begin(ctx, s, 62, R, 32768, 256, 2.0 * R * 32768 * 256, 2.0 * ((double)R * (256 + 32768) + 32768.0 * 256));
-    const int rc = launch_pw_dyn(s, pp);
+    const int rc = launch_pw_dyn(s, pp, h16);
     prof_end(rec, s);
     if (rc) { mcg_set_error("pw_single (dynamic_layer) launch failed"); return MCG_ERR_HIP; }
   } else if (chain_x3 && ctx.tile < 0 && pw_dyn_applicable(R) && (long long)R * 1024 < MCG_DMA_MAX_BYTES) {
@@ -629,7 +631,8 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
   } else {
     MCG_TRY(launch_linear(s, dt, w.x2, 256, W[MCG_SW_DYN_W], f32w[MCG_SW_DYN_B], nullptr, 0, w.params, 32768, R, 256, 32768, 0, ctx));
   }
-  if (bf) hipLaunchKernelGGL(dynconv_kernel<bf16_t>, dim3(R), dim3(256), 0, s, (const bf16_t*)roi_feat, (const bf16_t*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (bf16_t*)w.feat2);
+  if (h16) hipLaunchKernelGGL(dynconv_kernel<f16_t>, dim3(R), dim3(256), 0, s, (const f16_t*)roi_feat, (const f16_t*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (f16_t*)w.feat2);
+  else if (bf) hipLaunchKernelGGL(dynconv_kernel<bf16_t>, dim3(R), dim3(256), 0, s, (const bf16_t*)roi_feat, (const bf16_t*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (bf16_t*)w.feat2);
   else if (dt == MCG_F16X3) hipLaunchKernelGGL(dynconv_x3_kernel, dim3(R), dim3(256), 0, s, (const float*)roi_feat, (const float*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (float*)w.feat2);
   else hipLaunchKernelGGL(dynconv_kernel<float>, dim3(R), dim3(256), 0, s, (const float*)roi_feat, (const float*)w.params, f32w[MCG_SW_NORM_IN_G], f32w[MCG_SW_NORM_IN_B], f32w[MCG_SW_NORM_OUT_G], f32w[MCG_SW_NORM_OUT_B], (float*)w.feat2);
   MCG_CHECK_LAUNCH("dynconv");
@@ -672,7 +675,7 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
       st.g = f32w[MCG_SW_REG_LN_G] + j * 256; st.b = f32w[MCG_SW_REG_LN_B] + j * 256;
       st.from_input = j == 0; st.relu = 1; st.dst = j == 2 ? w.r1 : nullptr;
     }
-    if (bf ? launch_mlp_chain(s, cp) : launch_mlp_chain_x3(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
+    if (bf ? launch_mlp_chain(s, cp, h16) : launch_mlp_chain_x3(s, cp)) { mcg_set_error("mlp_chain launch failed"); return MCG_ERR_HIP; }
     rin = w.r1;
   } else {
     MCG_TRY(launch_linear(s, dt, obj_out, 256, W[MCG_SW_CLS_FC_W], nullptr, nullptr, 0, w.c1, 256, R, 256, 256, 0, ctx));
@@ -685,14 +688,15 @@ int stage_forward_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_SW_CO
     }
   }
   const float max_ratio = 4.135166556742356f;  // |log(16/1000)|, delta_xywh_bbox_coder.py:236
-  if (bf) hipLaunchKernelGGL(heads_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, (const bf16_t*)w.clsf, (const bf16_t*)rin, f32w[MCG_SW_HEAD_CLS_W], f32w[MCG_SW_HEAD_CLS_B], f32w[MCG_SW_HEAD_REG_W], f32w[MCG_SW_HEAD_REG_B], boxes_in, boxes_out, cls_out, R, stds[0], stds[1], stds[2], stds[3], max_ratio);
+  if (dt == MCG_BF16) hipLaunchKernelGGL(heads_kernel<bf16_t>, dim3((R + 3) / 4), dim3(256), 0, s, (const bf16_t*)w.clsf, (const bf16_t*)rin, f32w[MCG_SW_HEAD_CLS_W], f32w[MCG_SW_HEAD_CLS_B], f32w[MCG_SW_HEAD_REG_W], f32w[MCG_SW_HEAD_REG_B], boxes_in, boxes_out, cls_out, R, stds[0], stds[1], stds[2], stds[3], max_ratio);
+  else if (dt == MCG_F16) hipLaunchKernelGGL(heads_kernel<f16_t>, dim3((R + 3) / 4), dim3(256), 0, s, (const f16_t*)w.clsf, (const f16_t*)rin, f32w[MCG_SW_HEAD_CLS_W], f32w[MCG_SW_HEAD_CLS_B], f32w[MCG_SW_HEAD_REG_W], f32w[MCG_SW_HEAD_REG_B], boxes_in, boxes_out, cls_out, R, stds[0], stds[1], stds[2], stds[3], max_ratio);
   else hipLaunchKernelGGL(heads_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, s, (const float*)w.clsf, (const float*)rin, f32w[MCG_SW_HEAD_CLS_W], f32w[MCG_SW_HEAD_CLS_B], f32w[MCG_SW_HEAD_REG_W], f32w[MCG_SW_HEAD_REG_B], boxes_in, boxes_out, cls_out, R, stds[0], stds[1], stds[2], stds[3], max_ratio);
   MCG_CHECK_LAUNCH("heads");
   return MCG_OK;
 }
 
 extern "C" size_t mcg_gaze_head_workspace_bytes(mcg_dtype dt, int num_frames) {
-  const size_t es = dt == MCG_BF16 ? 2 : 4;
+  const size_t es = mcg_is16(dt) ? 2 : 4;
   return 3 * al256((size_t)6 * num_frames * 256 * es);
 }
 
@@ -705,7 +709,7 @@ int gaze_head_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_GW_COUNT]
   MCG_CHECK_ARG(W && obj && gaze_out && ws && N > 0, "mcg_gaze_head: bad argument");
   for (int i = 0; i < MCG_GW_COUNT; ++i) MCG_CHECK_ARG(W[i], "mcg_gaze_head: weight table entry %d is null", i);
   if (ws_bytes < mcg_gaze_head_workspace_bytes(dt, N)) { mcg_set_error("mcg_gaze_head: workspace too small"); return MCG_ERR_WORKSPACE; }
-  const size_t es = dt == MCG_BF16 ? 2 : 4;
+  const size_t es = mcg_is16(dt) ? 2 : 4;
   const size_t buf = al256((size_t)6 * N * 256 * es);
   char* raw = (char*)ws; char* h1 = raw + buf; char* h2 = h1 + buf;
   const char* fcw = (const char*)W[MCG_GW_FC_W];  // [6 branches = k*3+clue][2 layers][256][256]
@@ -729,6 +733,7 @@ int gaze_head_ctx(hipStream_t s, mcg_dtype dt, const void* const W[MCG_GW_COUNT]
     MCG_TRY(launch_ln(s, dt, q));
   }
   if (dt == MCG_BF16) hipLaunchKernelGGL(gaze_tail_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, (const bf16_t*)h2, (const float*)W[MCG_GW_OUT_W], (const float*)W[MCG_GW_OUT_B], (const float*)W[MCG_GW_FUSE_W], (const float*)W[MCG_GW_FUSE_B], gaze_out, N, cls_logits, scores_out);
+  else if (dt == MCG_F16) hipLaunchKernelGGL(gaze_tail_kernel<f16_t>, dim3((N + 3) / 4), dim3(256), 0, s, (const f16_t*)h2, (const float*)W[MCG_GW_OUT_W], (const float*)W[MCG_GW_OUT_B], (const float*)W[MCG_GW_FUSE_W], (const float*)W[MCG_GW_FUSE_B], gaze_out, N, cls_logits, scores_out);
   else hipLaunchKernelGGL(gaze_tail_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, (const float*)h2, (const float*)W[MCG_GW_OUT_W], (const float*)W[MCG_GW_OUT_B], (const float*)W[MCG_GW_FUSE_W], (const float*)W[MCG_GW_FUSE_B], gaze_out, N, cls_logits, scores_out);
   MCG_CHECK_LAUNCH("gaze_tail");
   return MCG_OK;
@@ -740,6 +745,7 @@ int launch_init_queries(hipStream_t s, mcg_dtype dt, const float* init_boxes, co
   const long long total = (long long)N * 3 * 256;
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (dt == MCG_BF16) hipLaunchKernelGGL(init_queries_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, init_boxes, (const bf16_t*)init_feats, img_hw, H, W, boxes, (bf16_t*)obj, N);
+  else if (dt == MCG_F16) hipLaunchKernelGGL(init_queries_kernel<f16_t>, dim3(grid), dim3(256), 0, s, init_boxes, (const f16_t*)init_feats, img_hw, H, W, boxes, (f16_t*)obj, N);
   else hipLaunchKernelGGL(init_queries_kernel<float>, dim3(grid), dim3(256), 0, s, init_boxes, (const float*)init_feats, img_hw, H, W, boxes, (float*)obj, N);
   MCG_CHECK_LAUNCH("init_queries");
   return MCG_OK;

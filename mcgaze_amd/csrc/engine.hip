@@ -135,7 +135,7 @@ static const std::vector<int>& side_streams_for(mcg_engine* e, hipStream_t s) {
 // window of the contraction kernel's buffer descriptors (beyond it every conv would fall back to the slower register-staged
 // kernel): 1337 frames at 224x224 bf16.  The `max_range_frames` option lowers the cap (tests).
 static int range_frame_cap(const mcg_engine* e, int H, int W) {
-  const long long per_frame = (long long)(H / 4) * (W / 4) * 256 * (e->dt == MCG_BF16 ? 2 : 4);
+  const long long per_frame = (long long)(H / 4) * (W / 4) * 256 * (mcg_is16(e->dt) ? 2 : 4);
   long long cap = 0x7FFFFF00ll / (per_frame > 0 ? per_frame : 1);
   if (e->max_range_frames > 0 && e->max_range_frames < cap) cap = e->max_range_frames;
   return cap < 1 ? 1 : (cap > 0x7fffffff ? 0x7fffffff : (int)cap);
@@ -149,12 +149,12 @@ static int trunk_ranges(const mcg_engine* e, int frames) {
 }
 
 static inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
-static inline size_t esize(mcg_dtype dt) { return dt == MCG_BF16 ? 2 : 4; }
+static inline size_t esize(mcg_dtype dt) { return mcg_is16(dt) ? 2 : 4; }
 
 extern "C" void mcg_engine_destroy(mcg_engine* e);
 extern "C" int mcg_engine_create(mcg_engine** out, const mcg_model_weights* w, mcg_dtype dt) {
   MCG_CHECK_ARG(out && w, "mcg_engine_create: null pointer");
-  MCG_CHECK_ARG(dt == MCG_F32 || dt == MCG_BF16 || dt == MCG_F16X3, "mcg_engine_create: unknown dtype %d", (int)dt);
+  MCG_CHECK_ARG(dt == MCG_F32 || dt == MCG_BF16 || dt == MCG_F16X3 || dt == MCG_F16, "mcg_engine_create: unknown dtype %d", (int)dt);
   int expect = 0;
   for (int l = 0; l < 4; ++l) {
     MCG_CHECK_ARG(w->blocks[l] > 0, "mcg_engine_create: blocks[%d]=%d", l, w->blocks[l]);
@@ -212,7 +212,7 @@ extern "C" int mcg_engine_set_option(mcg_engine* e, const char* name, int value)
   else if (!strcmp(name, "winograd")) { MCG_CHECK_ARG(value >= 0 && value <= 2, "winograd must be 0, 1 or 2"); e->winograd = value; }
   else if (!strcmp(name, "wino_tile")) { MCG_CHECK_ARG(value >= -1 && value <= 3, "wino_tile must be -1 (by grid size) .. 3"); e->wino_tile = value; }
   else if (!strcmp(name, "range_audit")) {
-    MCG_CHECK_ARG(e->dt != MCG_BF16 || !value, "range_audit: f32-storage engines only (MCG_F32, MCG_F16X3)");
+    MCG_CHECK_ARG(!mcg_is16(e->dt) || !value, "range_audit: f32-storage engines only (MCG_F32, MCG_F16X3)");
     if (value && !e->audit_dev) {   // set-up, not the hot path: the only allocation the library ever makes
       if (hipMalloc((void**)&e->audit_dev, sizeof(unsigned long long) * 2 * mcg_engine::kAuditCap) != hipSuccess) { e->audit_dev = nullptr; mcg_set_error("range_audit: hipMalloc failed"); return MCG_ERR_HIP; }
     }
@@ -352,7 +352,7 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
   d.wscale = dt == MCG_F16X3 ? cw.wscale : 0.f;
   const long long M = (long long)n * h * w;
   const int rm = res ? res_mode : MCG_RES_NONE;
-  if (dt == MCG_BF16 && e->pw_single && e->ctx.tile < 0 && !e->ctx.staged && cw.wf && cw.bias && cw.k == 1 && cw.stride == 1 && cw.pad == 0 &&
+  if (mcg_is16(dt) && e->pw_single && e->ctx.tile < 0 && !e->ctx.staged && cw.wf && cw.bias && cw.k == 1 && cw.stride == 1 && cw.pad == 0 &&
       pw_single_applicable(cw.cin, cw.cout, rm, M, rm == MCG_RES_UPSAMPLE_ADD ? (long long)n * hr * wr : M) && M < 0x7fffffffll) {
     PwSingleParams pp;
     memset(&pp, 0, sizeof(pp));
@@ -362,7 +362,7 @@ static int conv_call(const mcg_engine* e, hipStream_t s, mcg_dtype dt, const mcg
     const double res_rows = rm == MCG_RES_NONE ? 0.0 : (rm == MCG_RES_ADD ? (double)M : (double)n * hr * wr);
     ProfRec* rec = prof_begin(e->ctx, s, 61, pp.M, cw.cout, cw.cin, 2.0 * M * cw.cin * cw.cout,
                               2.0 * ((double)M * (cw.cin + cw.cout) + res_rows * cw.cout + (double)cw.cin * cw.cout));
-    const int prc = launch_pw_single(s, pp, cw.cin, cw.cout, rm == MCG_RES_NONE ? 0 : (rm == MCG_RES_ADD ? 1 : 2));
+    const int prc = launch_pw_single(s, pp, cw.cin, cw.cout, rm == MCG_RES_NONE ? 0 : (rm == MCG_RES_ADD ? 1 : 2), dt == MCG_F16);
     prof_end(rec, s);
     if (prc) { mcg_set_error("pw_single launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
@@ -494,7 +494,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
       const mcg_conv_weights* c3w = has_ds ? (e->c3_ds[l].w ? &e->c3_ds[l] : nullptr) : &c3;
       const mcg_conv_weights* c1n = ci_next < (int)e->convs.size() ? &e->convs[ci_next] : nullptr;
       const int k2 = has_ds ? e->convs[ci + 3].cin : 0;
-      if (dt == MCG_BF16 && e->pw_pair && l == 0 && c3w && c1n && c3w->wf && c1n->wf && c3w->bias && c1n->bias && c1n->k == 1 && c1n->stride == 1 &&
+      if (mcg_is16(dt) && e->pw_pair && l == 0 && c3w && c1n && c3w->wf && c1n->wf && c3w->bias && c1n->bias && c1n->k == 1 && c1n->stride == 1 &&
           c1n->cin == c3.cout && pw_pair_applicable(c3.cin, k2, has_ds ? e->convs[ci + 3].stride : 1, c3.cout, c1n->cout, (long long)n * ho * wo) && (long long)n * ho * wo < 0x7fffffffll) {
         PwPairParams pp;
         memset(&pp, 0, sizeof(pp));
@@ -507,7 +507,7 @@ static int trunk_chunk(mcg_engine* e, hipStream_t s, const float* img, int f0, i
         // cfg 60: both contractions of the pair count (2 M (K C + C C2))
         ProfRec* rec = prof_begin(e->ctx, s, 60, pp.M, pp.C + pp.C2, pp.K1 + pp.K2, 2.0 * pp.M * ((double)(pp.K1 + pp.K2) * pp.C + (double)pp.C * pp.C2),
                                   2.0 * ((double)pp.M * (pp.K1 + pp.K2 + (has_ds ? 0 : pp.C) + pp.C + pp.C2) + (double)(pp.K1 + pp.K2) * pp.C + (double)pp.C * pp.C2));
-        const int prc = launch_pw_pair(s, pp);
+        const int prc = launch_pw_pair(s, pp, dt == MCG_F16);
         prof_end(rec, s);
         if (prc) { mcg_set_error("pw_pair launch failed"); return MCG_ERR_HIP; }
         o1_ready = true;

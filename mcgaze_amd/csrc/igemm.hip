@@ -207,7 +207,7 @@ int launch_igemm(hipStream_t s, mcg_dtype dt, const IgemmParams& p_in, int group
   MCG_CHECK_ARG(p.M > 0 && p.Cout > 0 && groups > 0, "igemm: empty problem (M=%d Cout=%d groups=%d)", p.M, p.Cout, groups);
   MCG_CHECK_ARG(dt == MCG_F16X3 || p.wscale == 1.f, "igemm: wscale is an MCG_F16X3 operand (got %g)", (double)p.wscale);
   if (dt == MCG_F16X3) return launch_x3(s, p, groups, ctx);
-  return dt == MCG_BF16 ? launch_typed<bf16_t>(s, p, groups, ctx) : launch_typed<float>(s, p, groups, ctx);
+  return dt == MCG_BF16 ? launch_typed<bf16_t>(s, p, groups, ctx) : (dt == MCG_F16 ? launch_typed<f16_t>(s, p, groups, ctx) : launch_typed<float>(s, p, groups, ctx));
 }
 
 static IgemmParams linear_params(const void* x, long long lda, const void* w, int M, int K, int Cout) {
@@ -232,8 +232,8 @@ int launch_linear(hipStream_t s, mcg_dtype dt, const void* x, long long lda, con
 int launch_linear_splitk(hipStream_t s, mcg_dtype dt, const void* x, long long lda, const void* w, float* partial,
                          int M, int K, int Cout, int want_slices, int* splitk_out, const McgCtx& ctx) {
   IgemmParams p = linear_params(x, lda, w, M, K, Cout);
-  const int es = dt == MCG_BF16 ? 2 : 4;
-  const bool dma = dt == MCG_BF16 && !ctx.staged;
+  const int es = mcg_is16(dt) ? 2 : 4;
+  const bool dma = mcg_is16(dt) && !ctx.staged;
   // K elements per K-tile of the kernel that will run: 32 (f16x3), 64-byte slices (bf16 DMA), 128- or 64-byte slices (register-staged)
   const int bk = dt == MCG_F16X3 ? 32 : (dma ? 64 : (((long long)K * es) % 128 == 0 ? 128 : 64)) / es;
   const int KT = K / bk;
@@ -276,11 +276,11 @@ int conv2d_ctx(hipStream_t s, mcg_dtype dt, const mcg_conv_desc* d, const McgCtx
   }
   p.splitk = 1; p.tiles_per_slice = 1 << 30;
   p.wscale = d->wscale;
-  if (dt == MCG_BF16 && d->bias && ctx.c64 && !ctx.staged && ctx.tile < 0 &&
+  if (mcg_is16(dt) && d->bias && ctx.c64 && !ctx.staged && ctx.tile < 0 &&
       conv3x3_c64_applicable(d->KH, d->KW, d->stride, d->pad, d->Cin, d->Cout, p.res_mode != MCG_RES_NONE, d->x2 != nullptr)) {
     // layer1's conv2: window staged once, nine taps by address (conv3x3_c64.hpp); bit-identical to the generic kernel
     ProfRec* rec = prof_begin(ctx, s, 40, p.M, 64, 576, 2.0 * p.M * 64 * 576, algo_bytes(p, 1, 2));
-    const int rc = launch_conv3x3_c64(s, d->x, d->w, d->bias, d->y, d->N, d->H, d->W, d->relu);
+    const int rc = launch_conv3x3_c64(s, d->x, d->w, d->bias, d->y, d->N, d->H, d->W, d->relu, dt == MCG_F16);
     prof_end(rec, s);
     if (rc) { mcg_set_error("conv3x3_c64 launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
@@ -354,7 +354,7 @@ static inline int grid_for(long long total, int block) {
 }
 
 extern "C" size_t mcg_stem_workspace_bytes(mcg_dtype dt, int N, int H, int W) {
-  const size_t es = dt == MCG_BF16 ? 2 : 4;
+  const size_t es = mcg_is16(dt) ? 2 : 4;
   const size_t packed = (size_t)N * (H + 6) * (W + 8) * 4 * es;
   const size_t conv = (size_t)N * (H / 2) * (W / 2) * 64 * es;
   return ((packed + 255) / 256) * 256 + ((conv + 255) / 256) * 256;
@@ -372,20 +372,21 @@ int stem_forward_ctx(hipStream_t s, mcg_dtype dt, const float* img, const void* 
     mcg_set_error("mcg_stem_forward: workspace too small (%zu < %zu)", ws_bytes, mcg_stem_workspace_bytes(dt, N, H, W));
     return MCG_ERR_WORKSPACE;
   }
-  if (dt == MCG_BF16 && ctx.stem_fused) {  // one kernel, no conv-map round trip (stem_fused.hpp); bit-identical to the path below
-    if (launch_stem_fused(s, img, w_stem, bias, y, N, H, W)) { mcg_set_error("stem_fused launch failed"); return MCG_ERR_HIP; }
+  if (mcg_is16(dt) && ctx.stem_fused) {  // one kernel, no conv-map round trip (stem_fused.hpp); bit-identical to the path below
+    if (launch_stem_fused(s, img, w_stem, bias, y, N, H, W, dt == MCG_F16)) { mcg_set_error("stem_fused launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
   }
   if (dt == MCG_F16X3 && ctx.stem_fused) {  // the f16x3 form of the same kernel; bit-identical to the three launches below
     if (launch_stem_fused_x3(s, img, w_stem, bias, y, N, H, W)) { mcg_set_error("stem_fused (f16x3) launch failed"); return MCG_ERR_HIP; }
     return MCG_OK;
   }
-  const size_t es = dt == MCG_BF16 ? 2 : 4;
+  const size_t es = mcg_is16(dt) ? 2 : 4;
   const int Hp = H + 6, Wp = W + 8, Hc = H / 2, Wc = W / 2;
   char* packed = (char*)ws;
   char* conv = packed + (((size_t)N * Hp * Wp * 4 * es + 255) / 256) * 256;
   const long long npix = (long long)N * Hp * Wp;
   if (dt == MCG_BF16) hipLaunchKernelGGL(stem_pack_kernel<bf16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, s, img, (bf16_t*)packed, N, H, W, Hp, Wp);
+  else if (dt == MCG_F16) hipLaunchKernelGGL(stem_pack_kernel<f16_t>, dim3(grid_for(npix, 256)), dim3(256), 0, s, img, (f16_t*)packed, N, H, W, Hp, Wp);
   else hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(grid_for(npix, 256)), dim3(256), 0, s, img, (float*)packed, N, H, W, Hp, Wp);
   MCG_CHECK_LAUNCH("stem_pack");
   IgemmParams p;
@@ -399,6 +400,7 @@ int stem_forward_ctx(hipStream_t s, mcg_dtype dt, const float* img, const void* 
   const int Ho = (Hc + 2 - 3) / 2 + 1, Wo = (Wc + 2 - 3) / 2 + 1;
   const long long nchunks = (long long)N * Ho * Wo * (64 / (16 / (int)es));
   if (dt == MCG_BF16) hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(grid_for(nchunks, 256)), dim3(256), 0, s, (const bf16_t*)conv, (bf16_t*)y, N, Hc, Wc, 64, Ho, Wo);
+  else if (dt == MCG_F16) hipLaunchKernelGGL(maxpool3x3s2_kernel<f16_t>, dim3(grid_for(nchunks, 256)), dim3(256), 0, s, (const f16_t*)conv, (f16_t*)y, N, Hc, Wc, 64, Ho, Wo);
   else hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(nchunks, 256)), dim3(256), 0, s, (const float*)conv, (float*)y, N, Hc, Wc, 64, Ho, Wo);
   MCG_CHECK_LAUNCH("maxpool");
   return MCG_OK;
@@ -441,6 +443,7 @@ extern "C" int mcg_nchw_to_nhwc(mcg_stream s, mcg_dtype dt, const float* src, vo
   MCG_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "mcg_nchw_to_nhwc: bad argument");
   dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
   if (dt == MCG_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, src, (bf16_t*)dst, C, H * W);
+  else if (dt == MCG_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, src, (f16_t*)dst, C, H * W);
   else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, src, (float*)dst, C, H * W);
   MCG_CHECK_LAUNCH("nchw_to_nhwc");
   return MCG_OK;
@@ -449,6 +452,7 @@ extern "C" int mcg_nhwc_to_nchw(mcg_stream s, mcg_dtype dt, const void* src, flo
   MCG_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "mcg_nhwc_to_nchw: bad argument");
   dim3 grid((H * W + 31) / 32, (C + 31) / 32, N);
   if (dt == MCG_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)src, dst, C, H * W);
+  else if (dt == MCG_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, (const f16_t*)src, dst, C, H * W);
   else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)src, dst, C, H * W);
   MCG_CHECK_LAUNCH("nhwc_to_nchw");
   return MCG_OK;

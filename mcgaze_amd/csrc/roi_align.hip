@@ -96,10 +96,12 @@ int launch_roi_align(hipStream_t s, mcg_dtype dt, const void* const feats[4], co
     lv.feat[i] = feats[i]; lv.h[i] = feat_h[i]; lv.w[i] = feat_w[i];
     lv.scale[i] = 1.0f / (float)strides[i];
   }
-  const int epc = dt == MCG_BF16 ? 8 : 4;
+  const int epc = mcg_is16(dt) ? 8 : 4;
   MCG_CHECK_ARG(C % epc == 0 && C / epc <= 256 && 256 % (C / epc) == 0, "roi_align: unsupported channel count %d", C);
   if (dt == MCG_BF16)
     hipLaunchKernelGGL(roi_align_kernel<bf16_t>, dim3(num_boxes), dim3(256), 0, s, lv, C, boxes, boxes_per_frame, (bf16_t*)out, levels_out, 56.f);
+  else if (dt == MCG_F16)
+    hipLaunchKernelGGL(roi_align_kernel<f16_t>, dim3(num_boxes), dim3(256), 0, s, lv, C, boxes, boxes_per_frame, (f16_t*)out, levels_out, 56.f);
   else
     hipLaunchKernelGGL(roi_align_kernel<float>, dim3(num_boxes), dim3(256), 0, s, lv, C, boxes, boxes_per_frame, (float*)out, levels_out, 56.f);
   MCG_CHECK_LAUNCH("roi_align");

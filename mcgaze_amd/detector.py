@@ -318,7 +318,7 @@ class MultiClueGaze(nn.Module):
     reference's ``forward_train``); without it the N frames form ONE clip, as in the reference.
     ``precision`` is an attribute of the model: 'f16x3' (DEFAULT: f32 activations, split-fp16 x 3 MFMA contraction -- meets the
     reference's fp32 results to < 1e-4 rad on (yaw, pitch), i.e. the engine to evaluate a checkpoint with), 'fp32' (f32 MFMA,
-    the exact reference mode) or 'bf16' (throughput mode; an explicit opt-in, its deviation from the fp32 reference is not
+    the exact reference mode) or 'f16' / 'bf16' (16-bit throughput modes in fp16 / bf16; an explicit opt-in, its deviation from the fp32 reference is not
     within the 1e-3 parity tolerance)."""
 
     def __init__(self, backbone, rpn_head, roi_head, train_cfg, test_cfg, neck=None, pretrained=None, init_cfg=None):

@@ -14,13 +14,14 @@ from .packing import PackedWeights
 
 # precision -> (storage dtype of activations, mcg_dtype code).  'f16x3': f32 storage, split-fp16 x 3 MFMA contraction (parity-grade
 # fast mode, include/mcgaze_hip.h MCG_F16X3)
-_TORCH_DT = {'bf16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32, 'f16x3': torch.float32, 'bf16x3': torch.float32}
-_CODE = {'bf16': L.MCG_BF16, 'fp32': L.MCG_F32, 'f32': L.MCG_F32, 'f16x3': L.MCG_F16X3,
+# 'f16' (round 6): the 16-bit throughput mode in fp16 -- bf16's kernels and layouts with 11 significant bits instead of 8 (MCG_F16)
+_TORCH_DT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'fp16': torch.float16, 'fp32': torch.float32, 'f32': torch.float32, 'f16x3': torch.float32, 'bf16x3': torch.float32}
+_CODE = {'bf16': L.MCG_BF16, 'f16': L.MCG_F16, 'fp16': L.MCG_F16, 'fp32': L.MCG_F32, 'f32': L.MCG_F32, 'f16x3': L.MCG_F16X3,
          'bf16x3': L.MCG_F16X3}   # 'bf16x3': the engine's name while its halves were bf16 -- accepted, runs the fp16-halves engine
 
 
 def _code(dtype):
-    return L.MCG_BF16 if dtype == torch.bfloat16 else L.MCG_F32
+    return L.MCG_BF16 if dtype == torch.bfloat16 else (L.MCG_F16 if dtype == torch.float16 else L.MCG_F32)
 
 
 def _ptr(t):
@@ -269,7 +270,7 @@ class HipEngine:
                 return None
             tab = (C.c_void_p * 4)()
             L.check(self.lib.mcg_bench_backbone_levels(self._handle, _ptr(ws), N, H, W, tab), 'mcg_bench_backbone_levels')
-            es = ws.element_size() * (2 if self.dtype == torch.bfloat16 else 4)
+            es = ws.element_size() * (2 if self.dtype in (torch.bfloat16, torch.float16) else 4)
             out = []
             for i in range(4):
                 shape = (N, (H // 4) >> i, (W // 4) >> i, 256 << i)

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MCGAZE_LIB') or os.path.join(_HERE, 'libmcgaze_hip.so')   # MCGAZE_LIB: A/B a second build on one box
 
 MCG_OK = 0
-MCG_F32, MCG_BF16, MCG_F16X3 = 0, 1, 2
+MCG_F32, MCG_BF16, MCG_F16X3, MCG_F16 = 0, 1, 2, 3
 ABI_VERSION = 13
 RES_NONE, RES_ADD, RES_UPSAMPLE_ADD = 0, 1, 2
 FLAG_STAGED_GEMM, FLAG_NO_SPECIALISED, FLAG_NO_ATTN_BLOCK = 1, 2, 4

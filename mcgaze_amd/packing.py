@@ -223,7 +223,7 @@ class PackedWeights:
                         wf4=wf4(wo.permute(0, 3, 1, 2)) if wf4 is not None else None)
         vec = lambda t: self._dev(t.float())
         # fragment-major copies of the 1x1 convs (bf16 engine): operands of the register-resident-weight kernels (pw_pair.hpp, pw_single.hpp)
-        if dtype == torch.bfloat16:
+        if dtype in (torch.bfloat16, torch.float16):   # the 16-bit engines (MCG_BF16 / MCG_F16 share every layout)
             wf1x1 = lambda w: self._dev(frag_major(w.reshape(w.shape[0], -1).to(dtype)))
         elif split:   # f16x3: split fragment-major copies for the shapes pw_single_x3.hpp serves (256 -> 256 / 1024)
             wf1x1 = lambda w: (self._dev(frag_major_split(w.reshape(w.shape[0], -1))) if (w.shape[1] == 256 and w.shape[0] in (256, 1024) and w.reshape(w.shape[0], -1).shape[1] == 256) else None)
@@ -292,7 +292,7 @@ class PackedWeights:
             self.fpn_out.append(entry(w, sd[f'neck.fpn_convs.{i}.conv.bias'], 3, 1, 1, wf=wf3x3, wf4=wf3x3_g4))
         self.init_boxes = vec(sd['rpn_head.init_proposal_bboxes.weight'])
         self.init_feats = self._dev(sd['rpn_head.init_proposal_features.weight'].to(dtype))   # read by a non-GEMM kernel: storage dtype
-        perm = dyn_permutation(epc=8 if (dtype == torch.bfloat16 or split) else 4)   # f16x3: dynconv_x3_kernel takes eight K elements per lane and step
+        perm = dyn_permutation(epc=8 if (dtype in (torch.bfloat16, torch.float16) or split) else 4)   # f16x3: dynconv_x3_kernel takes eight K elements per lane and step
         self.stages = []
         for s in range(num_stages):
             p = f'roi_head.bbox_head.{s}'
@@ -323,7 +323,7 @@ class PackedWeights:
                        REG_FC_W=torch.stack([sd[p + f'.reg_fcs.{3 * j}.weight'] for j in range(3)]),
                        DYN_W=sd[q + '.dynamic_layer.weight'][perm])
             for k in ('OUT_PROJ_W', 'CLS_FC_W', 'REG_FC_W', 'IN_PROJ_W', 'DYN_W'):   # fragment-major copies for the fused chain / attention-block kernels
-                if dtype == torch.bfloat16:
+                if dtype in (torch.bfloat16, torch.float16):
                     st[k + 'F'] = frag_major(st[k])
                 elif split and k in raw:
                     st[k + 'F'] = self._dev(frag_major_split(raw[k]))              # f16x3: the chains' split fragment-major operands (chain_x3.hpp)

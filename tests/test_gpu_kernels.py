@@ -15,8 +15,8 @@ from oracle import mcgaze_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
-DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2, torch.float16: 2.5e-3}
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def scale_err(a, b):
@@ -686,17 +686,18 @@ def test_roi_align_hip_equals_scalar_statement(eng):
     assert worst < 2e-5
 
 
-KINDS = ['fp32', 'f16x3', 'bf16']   # engine kinds of the whole-operator tests below
-KIND_DTYPE = {'fp32': torch.float32, 'f16x3': torch.float32, 'bf16': torch.bfloat16}
+KINDS = ['fp32', 'f16x3', 'bf16', 'f16']   # engine kinds of the whole-operator tests below ('f16': MCG_F16, round 6)
+KIND_DTYPE = {'fp32': torch.float32, 'f16x3': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
 # Per-operator bounds as a fraction of the tensor's scale: measured worst case over the parametrised cases x 1.5 (printed by the tests).
 # fp32: only the summation order differs from the CPU reference.  f16x3: operands carry 22 bits (bf16 halves, the first version: 16-17 bits,
 # bounds 2.5e-5 / 4.5e-5 / 3e-5).  bf16: 8 bits on operands and
 # stored activations.
 STAGE_TOL = {'fp32': dict(obj=2e-6, cls=2e-6, boxes=1e-6),          # measured <= 1.0e-6 / 1.3e-6 / 5.7e-7
              'f16x3': dict(obj=3.5e-6, cls=4.5e-6, boxes=9e-7),    # measured <= 2.1e-6 / 3.0e-6 / 5.7e-7
-             'bf16': dict(obj=1.5e-2, cls=2e-2, boxes=6e-3)}        # measured <= 9.6e-3 / 1.3e-2 / 4.0e-3 (round 1 allowed 6e-2)
-GAZE_TOL = {'fp32': 2e-6, 'f16x3': 3.5e-6, 'bf16': 4e-2}           # measured 1.1e-6 / 2.2e-6 / 2.7e-2 (absolute, unit vectors)
-PYRAMID_TOL = {'fp32': 4e-6, 'f16x3': 5e-6, 'bf16': 1.7e-2}        # measured <= 2.6e-6 / 3.2e-6 / 1.13e-2 (round 1 allowed 5e-2)
+             'bf16': dict(obj=1.5e-2, cls=2e-2, boxes=6e-3),        # measured <= 9.6e-3 / 1.3e-2 / 4.0e-3 (round 1 allowed 6e-2)
+             'f16': dict(obj=2.5e-3, cls=3e-3, boxes=1e-3)}         # fp16 storage: bf16's bounds / 6 (three more bits would be / 8)
+GAZE_TOL = {'fp32': 2e-6, 'f16x3': 3.5e-6, 'bf16': 4e-2, 'f16': 7e-3}           # measured 1.1e-6 / 2.2e-6 / 2.7e-2 (absolute, unit vectors)
+PYRAMID_TOL = {'fp32': 4e-6, 'f16x3': 5e-6, 'bf16': 1.7e-2, 'f16': 3e-3}        # measured <= 2.6e-6 / 3.2e-6 / 1.13e-2 (round 1 allowed 5e-2)
 
 
 @pytest.mark.parametrize('kind', KINDS)
@@ -724,19 +725,20 @@ def test_decoder_stage(eng, sd, kind, B, T):
             assert v < STAGE_TOL[kind][k], (k, v)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('B,T', [(1, 7), (5, 3), (11, 1), (2, 10), (1, 11), (13, 7), (64, 7)])
-def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T):
-    """attn_block.hpp (both attention passes of a stage as one launch, one clip per workgroup, for 3 T <= 32; T = 11 takes the
+def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T, dtype):
+    """(bf16 and, round 6, the fp16 instantiations of the same templates.)  attn_block.hpp (both attention passes of a stage as one launch, one clip per workgroup, for 3 T <= 32; T = 11 takes the
     per-pass chain) and chain.hpp (towers and attention out-projection + LayerNorm as single launches) keep the K order, the bf16 rounding points
     and the LayerNorm reduction order of the launch sequence it replaces -- incl. row counts that are not a multiple of its 32-row
     block.  From 256 tokens on, `dynamic_layer` runs through pw_single.hpp (128 column slices with register-resident weights, tokens streamed in
     32-row tiles): 13 x 7 frames give 273 tokens = eight full tiles and one of 17 rows."""
     from mcgaze_amd.packing import PackedWeights
-    pw = PackedWeights(sd, dtype=torch.bfloat16)
+    pw = PackedWeights(sd, dtype=dtype)
     N = B * T
     g = torch.Generator().manual_seed(300 + N)
-    roi = (torch.randn(N * 3, 49, 256, generator=g) * 3).to(torch.bfloat16).to('cuda:0')
-    obj = torch.randn(N, 3, 256, generator=g).to(torch.bfloat16).to('cuda:0')
+    roi = (torch.randn(N * 3, 49, 256, generator=g) * 3).to(dtype).to('cuda:0')
+    obj = torch.randn(N, 3, 256, generator=g).to(dtype).to('cuda:0')
     boxes = (torch.tensor([[20., 30., 200., 210.], [60., 50., 160., 150.], [90., 60., 130., 100.]])[None].repeat(N, 1, 1) + torch.randn(N, 3, 4, generator=g)).to('cuda:0')
     outs = {}
     from mcgaze_amd import lib as L
@@ -744,7 +746,19 @@ def test_mlp_chain_matches_unfused_bitwise(eng, sd, B, T):
         outs[mode] = [t.clone() for t in eng.stage_forward(pw.stages[1], roi, obj, boxes, T, flags=flags)]
     torch.cuda.synchronize()
     for a, b, name in zip(outs['0'], outs['1'], ('obj', 'boxes', 'cls')):
-        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b), name
+        same = torch.equal(a.view(torch.int16) if a.element_size() == 2 else a, b.view(torch.int16) if b.element_size() == 2 else b)
+        ndiff, dmax = int((a.float() != b.float()).sum()), float((a.float() - b.float()).abs().max())
+        if dtype == torch.bfloat16:
+            assert same, (name, f'{ndiff} of {a.numel()} elements differ, max |d| = {dmax:.3e}')
+        else:
+            # fp16: NOT bit-identical from a few hundred tokens on.  Measured (profiles/r06_f16_engine.md): the fused and the unfused decoder sequences agree
+            # bit for bit up to 60 tokens and differ by ONE fp16 ulp in 0.2 - 4 % of the query features at 273 - 1344 tokens (13 x 7: 145 of 69 888) --
+            # f32-level differences between the two instruction sequences that an 11-bit rounding exposes eight times as often as bf16's 8-bit one
+            # (bf16: 0 differences on every case).  What the product needs holds bit for bit: a clip's result does not depend on its batch
+            # (test_batched_equals_per_clip_bitwise, test_full_batch_properties[f16]); this is an A / B option of a throughput engine.
+            scale = float(a.float().abs().max())
+            print(f'f16 B={B} T={T} {name}: {ndiff} of {a.numel()} elements differ, max |d| = {dmax:.3e} (scale {scale:.2f})')
+            assert same or (ndiff <= 0.06 * a.numel() and dmax <= 2.5e-3 * max(scale, 1.0)), (name, ndiff, dmax)
 
 
 @pytest.mark.parametrize('B,T', [(1, 7), (5, 3), (11, 1), (2, 10), (1, 11), (13, 7), (64, 7)])

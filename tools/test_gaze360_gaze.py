@@ -2,7 +2,7 @@
 """Dataset inference with the reference's command line (its tools/test_gaze360_gaze.py:20-44):
 
     python tools/test_gaze360_gaze.py <config> <checkpoint> --json data/gaze360/test.json --root data/gaze360/test_rawframes/ \
-        [--device cuda:0] [--cfg-options k=v ...] [--precision f16x3|fp32|bf16] [--batch-clips 64] [--seed S] [--anno gt.json]
+        [--device cuda:0] [--cfg-options k=v ...] [--precision f16x3|fp32|f16|bf16] [--batch-clips 64] [--seed S] [--anno gt.json]
 
 Every video of the annotation file is cut into 7-frame windows (stride 4), the frames of each window go through
 cfg.data.test.pipeline on the device (mcgaze_amd.pipeline), all windows run through the HIP engine in batches of --batch-clips
@@ -52,8 +52,8 @@ def parse_args(argv=None):
     ap.add_argument('--root', default='data/gaze360/test_rawframes/', help='Path to image file')
     ap.add_argument('--device', default='cuda:0', help='Device used for inference')
     ap.add_argument('--cfg-options', nargs='+', default=None, help='k=v overrides merged into the config (mmcv DictAction syntax)')
-    ap.add_argument('--precision', default='f16x3', choices=['f16x3', 'fp32', 'bf16'],
-                    help="'f16x3' (default): parity-grade fast engine; 'fp32': exact reference mode; 'bf16': throughput mode (not within the 1e-3 tolerance)")
+    ap.add_argument('--precision', default='f16x3', choices=['f16x3', 'fp32', 'f16', 'bf16'],
+                    help="'f16x3' (default): parity-grade fast engine; 'fp32': exact reference mode; 'f16' / 'bf16': 16-bit throughput modes in fp16 / bf16 (not within the 1e-3 tolerance; fp16 is eight times closer)")
     ap.add_argument('--batch-clips', type=int, default=64)
     ap.add_argument('--seed', type=int, default=None)
     ap.add_argument('--per-video-seed', action='store_true',
