@@ -997,9 +997,22 @@ def main():
             pf = json.load(open(pfp))
             if a.precision in pf:
                 line['parity_fuzz'] = {'n': pf[a.precision]['n'], 'within': pf[a.precision]['within'], 'worst_rad': pf[a.precision]['worst_rad'],
+                                       'median_rad': pf[a.precision].get('median_rad'),
+                                       'trained_family': {k: (pf.get('trained_family') or {}).get(a.precision, {}).get(k) for k in ('n', 'within', 'worst_rad', 'median_rad')} if pf.get('trained_family') else None,
                                        'build_id': pf.get('build_id'), 'build_matches': pf.get('build_id') == _lib.build_id(),
                                        'source': 'profiles/parity_fuzz.json: tools/parity_fuzz.py (random shapes, clip lengths, weight seeds) vs the CPU oracle, tolerance 1e-3 rad; '
                                                  'the inputs beyond it are pinned as tests (tests/test_gpu_forward.py::test_known_fuzz_exceptions_stay_what_they_are)'}
+        if os.path.exists(pfp) and not a.fake_engine:
+            # the throughput engines in the same fuzz (committed evidence, like the headline's): how far OUTSIDE 1e-3 they are, per population
+            pf = json.load(open(pfp))
+            from mcgaze_amd import lib as _lib
+            for tgt in [second] + list(others.values()):
+                if tgt is not None and tgt['dtype'] in pf and tgt['dtype'] != a.precision:
+                    e = pf[tgt['dtype']]
+                    tgt['parity_fuzz'] = {'n': e['n'], 'within': e['within'], 'worst_rad': e['worst_rad'], 'median_rad': e.get('median_rad'),
+                                          'trained_family': (pf.get('trained_family') or {}).get(tgt['dtype']),
+                                          'build_id': pf.get('build_id'), 'build_matches': pf.get('build_id') == _lib.build_id(),
+                                          'source': 'profiles/parity_fuzz.json (tools/parity_fuzz.py vs the CPU oracle, tolerance 1e-3 rad): a THROUGHPUT engine -- this object says how far outside the tolerance it is'}
         if 'rccl_ranks_verified' in head:
             line['rccl_ranks_verified'] = head['rccl_ranks_verified']
             line['rccl_verified_how'] = verify_ring_neighbour.__doc__.split('->')[0].strip().replace('\n    ', ' ')
