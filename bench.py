@@ -787,6 +787,11 @@ def power_probe(leg, seconds=1.5):
     leg.run_for(0.3)                        # clocks settled before the first sample
     th.start()
     n, el = leg.run_for(seconds)
+    for _ in range(6):                      # a box whose rocm-smi call takes a second yields one sample per second: keep the schedule running until there are a few
+        if len(samples) >= 4:
+            break
+        n2, el2 = leg.run_for(1.0)
+        n, el = n + n2, el + el2
     stop.set()
     th.join(timeout=10)
     s = samples[1:-1] if len(samples) > 4 else samples

@@ -94,7 +94,7 @@ def test_fp32_engine_matches_reference_golden(golden_dir, engines, engines_train
         boxes = boxes / torch.from_numpy(g['scale_factor'])[None, None, :]
     dbox = float(np.abs(boxes.numpy() - g['det_bboxes'][..., :4]).max())
     print(f'{name} {precision} boxes: max |d| = {dbox:.2e} px (coordinates up to {float(np.abs(g["det_bboxes"][..., :4]).max()):.0f} px)')
-    # boxes against the REFERENCE's: measured <= 1.3e-3 px on coordinates of several hundred px (both engines, all goldens); 5e-3 px absolute
+    # boxes against the REFERENCE's: measured <= 2.0e-3 px (f16x3, the non-square golden; fp32 <= 1.1e-3) on coordinates up to 450 px, all goldens; 5e-3 px absolute
     np.testing.assert_allclose(boxes.numpy(), g['det_bboxes'][..., :4], atol=5e-3, rtol=0)
     np.testing.assert_allclose(out['scores'].cpu().numpy(), g['det_bboxes'][..., 4], atol=1e-3)
 
