@@ -76,3 +76,16 @@ from mcgaze_amd.engine import HipEngine
 eng = HipEngine(synth.make_state_dict(0), precision='f16x3')
 img = torch.from_numpy(synth.make_clips(3, N // 7, 7)).cuda()
 report('whole forward (trunk + decoder, one stream pair)', lambda: eng.forward(img, 7), 99.55e9 * (N // 7))
+report('trunk only (backbone + FPN, two frame ranges)', lambda: eng.backbone_fpn(img), 97.01e9 * (N // 7))
+# round 6: the decoder alone on precomputed pyramids, and the 16-bit throughput engines' whole forward
+from mcgaze_amd.engine import _ptr, _ws, _stream
+pyr = eng.backbone_fpn(img)
+tab = (C.c_void_p * 4)(*[p.data_ptr() for p in pyr])
+ws = _ws(eng.lib.mcg_decoder_workspace_bytes(eng._handle, N), eng.device)
+out = dict(gaze=torch.empty(4, N, 3, device='cuda'), boxes=torch.empty(N, 3, 4, device='cuda'), scores=torch.empty(N, 3, device='cuda'))
+report('decoder only (4 x [RoIAlign + stage] + gaze head)', lambda: L.check(eng.lib.mcg_decoder_forward(eng._handle, _stream(), tab, N, 7, 224, 224, None, _ptr(out['gaze']), _ptr(out['boxes']), _ptr(out['scores']), _ptr(ws), ws.numel()), 'dec'), 2.54e9 * (N // 7))
+del eng, pyr, ws
+for prec in ('f16', 'bf16'):
+    e16 = HipEngine(synth.make_state_dict(0), precision=prec)
+    report(f'whole forward, {prec} engine', lambda: e16.forward(img, 7), 99.55e9 * (N // 7))
+    del e16
