@@ -90,8 +90,8 @@ def parse():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--precision', default='f16x3', choices=['bf16', 'f16', 'fp32', 'f16x3'],
                     help='the HEADLINE engine; f16x3 (default) is the one inside north_star\'s 1e-3 tolerance')
-    ap.add_argument('--second-engine', '--parity-engine', dest='second_engine', default='f16,bf16',
-                    help="engines timed in the same run beside the headline, comma-separated (of bf16, f16, f16x3, fp32; 'none' = no second engine).  The first "
+    ap.add_argument('--second-engine', '--parity-engine', dest='second_engine', default=None,
+                    help="engines timed in the same run beside the headline, comma-separated (of bf16, f16, f16x3, fp32; default f16,bf16 -- none under --fake-engine; 'none' = no second engine).  The first "
                          "is reported as `throughput_engine` (default f16: fp16 storage and MFMA, MCG_F16), the others under `other_engines`; one equal to --precision is skipped")
     ap.add_argument('--exact-steps', type=int, default=10, help='timed steps of the exact_engine leg (fp32 engine, rank 0, N = 1 only; 0 disables)')
     ap.add_argument('--second-steps', '--parity-steps', dest='second_steps', type=int, default=0, help='timed steps of the second engine (0 = steps)')
@@ -839,8 +839,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run for N > 1'
-    if a.fake_engine:   # control-flow rehearsal on the host (tests/test_dist_cpu.py): no second engine, no GPU-only legs
-        a.second_engine, a.kernel_events, a.backbone_clips, a.mae_videos, a.host_input_steps, a.latency, a.cpu_seconds = 'none', 'none', 0, 0, 0, 0, 0.0
+    if a.second_engine is None:
+        a.second_engine = 'none' if a.fake_engine else 'f16,bf16'
+    if a.fake_engine:   # control-flow rehearsal on the host (tests/test_dist_cpu.py): second engines only when asked for (the same stand-in under another name:
+                        # what is rehearsed is N ranks walking through several engines' legs, collectives included, in step), no GPU-only legs
+        a.kernel_events, a.backbone_clips, a.mae_videos, a.host_input_steps, a.latency, a.cpu_seconds = 'none', 0, 0, 0, 0, 0.0
         a.power_seconds = 0.0
         a.exact_steps = 0
         dev = torch.device('cpu')

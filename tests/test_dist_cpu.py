@@ -141,6 +141,8 @@ def test_bench_control_flow_with_the_fake_engine(world):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', str(world), '--fake-engine', '--steps', '3', '--warmup', '1',
            '--clips-per-gpu', '2', '--size', '32', '--strong-clips', '8']
+    if world == 2:   # round 6: the driver's default line times three engines per rank (headline, throughput_engine, other_engines): every rank must walk them in step
+        cmd += ['--second-engine', 'f16,bf16']
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -152,3 +154,8 @@ def test_bench_control_flow_with_the_fake_engine(world):
     st = line['strong_scaling']
     assert st['global_clips'] == 8 and st['clips_per_gpu'] == 8 // world and st['scaling'] == 'strong' and st['value'] > 0
     assert line['config']['global_clips'] == 2 * world and 'FAKE ENGINE' in line['data']
+    if world == 2:
+        assert line['throughput_engine']['dtype'] == 'f16' and line['throughput_engine']['rccl_ranks_verified'] == world
+        assert list(line['other_engines']) == ['bf16'] and line['other_engines']['bf16']['rccl_ranks_verified'] == world
+    else:
+        assert 'throughput_engine' not in line
