@@ -110,6 +110,15 @@ def test_packed_weights_fused_tail_table():
     assert packing.PackedWeights(sd, dtype=torch.float32, device='cpu').fused == []
     st = w.stages[0]
     assert st['OUT_PROJ_WF'].dtype == torch.float16 and tuple(st['REG_FC_WF'].shape) == (3, 256, 512)
+    # ABI 13: the f16x3 attention block reads in_proj in the split fragment-major form (24 column tiles); the 16-bit engines the plain one, in THEIR format
+    assert st['IN_PROJ_WF'].dtype == torch.float16 and tuple(st['IN_PROJ_WF'].shape) == (768, 512)
+    assert torch.equal(st['IN_PROJ_WF'], packing.frag_major_split(torch.as_tensor(sd['roi_head.bbox_head.0.attention.attn.in_proj_weight'])))
+    for dt in (torch.bfloat16, torch.float16):
+        w16 = packing.PackedWeights(sd, dtype=dt, device='cpu')
+        s16 = w16.stages[0]
+        assert s16['IN_PROJ_WF'].dtype == dt and tuple(s16['IN_PROJ_WF'].shape) == (768, 256)
+        assert torch.equal(s16['IN_PROJ_WF'], packing.frag_major(torch.as_tensor(sd['roi_head.bbox_head.0.attention.attn.in_proj_weight']).to(dt)))
+        assert w16.convs[0]['w'].dtype == dt and w16.convs[0]['wf'] is not None and w16.convs[0]['wf'].dtype == dt    # MCG_F16 shares every layout with MCG_BF16
 
 
 def test_bench_roofline_bookkeeping():
