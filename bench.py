@@ -911,7 +911,11 @@ def main():
             bimg = torch.from_numpy(synth.make_clips(11, a.backbone_clips, T, a.size, a.size)).to(dev)
             bleg = Leg(a, precision, dev, 1, 0, None, bimg, a.backbone_clips, T, workload='backbone', engine=leg.eng)
             _, back = timed_leg(bleg, max(10, min(steps, 50)), 3, a.backbone_clips, FLOPS_PER_CLIP_BACKBONE, 1)
-            del bleg, bimg
+            # SURVEY.md 8(d) asks for both readings of "R-50 FPN backbone": the same batch through backbone + FPN (mcg_backbone_fpn_forward)
+            fleg = Leg(a, precision, dev, 1, 0, None, bimg, a.backbone_clips, T, workload='backbone_fpn', engine=leg.eng)
+            _, with_fpn = timed_leg(fleg, max(10, min(steps, 50)), 3, a.backbone_clips, FLOPS_PER_CLIP_TRUNK, 1)
+            back['with_fpn'] = {k: with_fpn[k] for k in ('value', 'unit', 'steps', 'ms_per_step', 'model_tflops', 'frac_of_bf16_mfma_peak')}
+            del bleg, fleg, bimg
         return leg, res, back
 
     WHAT = {'f16x3': 'f32 activations, weights split-packed into fp16 high / low halves, three fp16 MFMAs per product, f32 accumulate (include/mcgaze_hip.h MCG_F16X3); the library default',
@@ -1034,7 +1038,7 @@ def main():
             line['exact_engine'] = exact
         if head_back is not None:
             line['backbone'] = {'what': f'BASELINE.json configs[1]: R-50 backbone only (stem + layer1..4, C2..C5; mcg_bench_backbone_forward), {a.backbone_clips} clips x {T} frames x 3x{a.size}x{a.size}, '
-                                        f'{FLOPS_PER_CLIP_BACKBONE / 1e9:.2f} GFLOP per clip, two concurrent frame ranges', a.precision: head_back}
+                                        f'{FLOPS_PER_CLIP_BACKBONE / 1e9:.2f} GFLOP per clip, two concurrent frame ranges; `with_fpn`: the same batch through backbone + FPN ({FLOPS_PER_CLIP_TRUNK / 1e9:.2f} GFLOP per clip)', a.precision: head_back}
             if second_back is not None:
                 line['backbone'][a.second_engine] = second_back
             for pk, bk in others_back.items():
